@@ -1,0 +1,101 @@
+/*
+ * qeft_hip.h — C ABI of the MI355X (gfx950) packed-weight quantized linear.
+ *
+ * Drop-in boundary for the one hot path of xvyaward/qeft: the functions the
+ * reference binds in its `qeft_cuda` torch extension (qeft/kernel/qeft_cuda.cpp:10-27)
+ * for the W4 group-quantised linear with retained fp16 outlier columns.
+ * Plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ * noted; `stream` is a hipStream_t passed as void*.  No allocation, no
+ * synchronisation and no host<->device copy happens inside any entry point,
+ * so every call may be captured into a hipGraph.
+ *
+ * Buffers (reference checkpoint layout, qeft/qlinear.py:143-173):
+ *   qweight       int16 [N/4, K]      4 rows interleaved per 64-k tile, nibble order of
+ *                                     pack_intweight (qlinear.py:81-121)
+ *   scales        fp16  [K/g, N]
+ *   scaled_zeros  fp16  [K/g, N]      = -(zero * scale)
+ *   oweight       fp16  [N, r]        retained outlier columns (the LAST r input columns)
+ *   oweight_il    fp16  [N/2, 2r]     pack_oweight interleave (qlinear.py:70-79)
+ *   x             fp16  [m, K] row-major contiguous;  y fp16 [m, N]
+ *
+ * Every function returns QEFT_OK (0) or a QEFT_ERR_* code; qeft_error_string()
+ * gives the message.  Kernel-launch failures return QEFT_ERR_LAUNCH and the
+ * hipError_t is available from qeft_last_hip_error().
+ */
+#ifndef QEFT_HIP_H
+#define QEFT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QEFT_OK 0
+#define QEFT_ERR_BATCH 1  /* m outside 1..7 on a gemv entry: "Unsupported batch size for gemv kernel."
+                             (gemv_cuda_qeft.cu:466, gemv_cuda.cu:466) */
+#define QEFT_ERR_SHAPE 2  /* N % 4, K % 64, n_out % 32 ... */
+#define QEFT_ERR_GROUP 3  /* group size not a multiple of 32 dividing K */
+#define QEFT_ERR_NULL 4   /* required pointer is NULL */
+#define QEFT_ERR_LAUNCH 5 /* hip launch error, see qeft_last_hip_error() */
+#define QEFT_ERR_ALIGN 6  /* pointer not 16-byte aligned */
+
+typedef void* qeft_stream_t;
+
+int qeft_abi_version(void);
+const char* qeft_error_string(int code);
+int qeft_last_hip_error(void);
+
+/* Decode GEMV, m in 1..7, no outlier slice.
+ * Replaces gemv_4bit(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size)
+ * (qeft/kernel/quantization_new/gemv/gemv_cuda.cu:358-525). */
+int qeft_gemv_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                 void* y, int m, int n, int k, int group_size, qeft_stream_t stream);
+
+/* Decode GEMV with the fp16 outlier slice taken from the interleaved buffer.
+ * Replaces gemv_4bit_qeft(in_feats, kernel, scaling_factors, zeros, oweight_interleaved, m, n, k, group_size)
+ * (qeft/kernel/quantization_new/gemv/gemv_cuda_qeft.cu:392-513); n_out = oweight_il.size(1)/2 (:424). */
+int qeft_gemv_w4_qeft(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                      const void* oweight_il, void* y, int m, int n, int k, int group_size, int n_out,
+                      qeft_stream_t stream);
+
+/* Fused decode GEMV: everything QuantLinear.forward_* does around the kernel in one launch
+ * (qeft/qlinear.py:244-330): optional input gather x[:, reorder_ids] (:275, int32 ids, NULL = none),
+ * optional bias add (:268, NULL = none), optional residual add into y (y = acc + residual; NULL = none).
+ * oweight_il may be NULL when n_out == 0. */
+int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                       const void* oweight_il, const void* bias, const int* reorder_ids,
+                       const void* residual, void* y, int m, int n, int k, int group_size, int n_out,
+                       qeft_stream_t stream);
+
+/* Prefill / fine-tune GEMM  y[M,N] = x[M,K] . Wdeq[N,K]^T  on MFMA, fp32 accumulate, fp16 out.
+ * Replaces gemm_4bit(in_feats, kernel, scales, zeros) (qeft/kernel/quantization_new/gemm/gemm_cuda.cu:929-1033).
+ * With oweight == NULL the INT4 nibbles are used for every column (exactly gemm_4bit);
+ * with oweight != NULL the last n_out columns come from the fp16 slice inside the same launch — the fusion
+ * gemm_cuda_qeft.cu:1003 intended and qlinear.py:266 does with a second F.linear.  bias may be NULL. */
+int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                 const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size,
+                 int n_out, qeft_stream_t stream);
+
+/* Backward wrt the input: dx[M,K] = dy[M,N] . Wdeq[N,K]; columns K-n_out.. use oweight (SURVEY.md §8a row 7;
+ * the mathematically correct form of QuantMatMulQEFT.backward, qlinear.py:30-44). */
+int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
+                    const void* oweight, void* dx, int m, int n, int k, int group_size, int n_out,
+                    qeft_stream_t stream);
+
+/* Gradient of the trainable outlier slice: d_oweight[N, r] (fp32) = dy[M,N]^T . x[M, K-r:]  (qlinear.py:41-42). */
+int qeft_grad_oweight(const void* dy, const void* x, void* d_oweight_f32, int m, int n, int k, int n_out,
+                      qeft_stream_t stream);
+
+/* Dense dequantisation Wdeq[N,K] fp16 (validation / backward helper; the role of the uncompiled
+ * dequantize_weight_4bit_qeft, qeft/kernel/quantization_new/dequantize/dequantize_cuda_qeft.cu:38-118).
+ * oweight (plain [N, r]) may be NULL. */
+int qeft_dequant_w4(const void* qweight, const void* scales, const void* scaled_zeros, const void* oweight,
+                    void* w_out, int n, int k, int group_size, int n_out, qeft_stream_t stream);
+
+/* Re-derive the interleaved outlier buffer from oweight on device (pack_oweight, qlinear.py:70-79);
+ * used after fine-tuning so the GEMV never reads a stale copy (modelutils.py:192 quirk). */
+int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, qeft_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QEFT_HIP_H */

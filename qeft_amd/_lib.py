@@ -1,0 +1,58 @@
+"""ctypes binding of the C ABI in include/qeft_hip.h (qeft_amd/lib/libqeft_hip.so).
+
+There is no CPU fallback: if the library is missing, or an entry point fails, the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqeft_hip.so")
+
+_p, _i = ctypes.c_void_p, ctypes.c_int
+
+# name -> argtypes, exactly as declared in include/qeft_hip.h
+SIGNATURES = {
+    "qeft_abi_version": [],
+    "qeft_error_string": [_i],
+    "qeft_last_hip_error": [],
+    "qeft_gemv_w4": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "qeft_gemv_w4_qeft": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemv_w4_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemm_w4": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemm_w4_dx": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_grad_oweight": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "qeft_dequant_w4": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "qeft_pack_oweight": [_p, _p, _i, _i, _p],
+}
+
+_lib = None
+
+
+class QeftHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QeftHipError(
+                f"{LIB_PATH} not found: build it with `python -m qeft_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the quantized linear.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "qeft_error_string" else _i
+        _lib = l
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        l = lib()
+        msg = l.qeft_error_string(code).decode()
+        if code == 5:
+            msg += f" (hipError_t={l.qeft_last_hip_error()})"
+        raise QeftHipError(msg)

@@ -1,0 +1,357 @@
+// Prefill / fine-tune GEMMs for the QEFT packed W4 (+ fp16 outlier slice) linear on gfx950 MFMA.
+//
+// Replaces gemm_w4a16_T1/T2 (qeft/kernel/quantization_new/gemm/gemm_cuda.cu:290-927) and delivers the
+// fused-outlier GEMM that gemm_cuda_qeft.cu only sketched (qlinear.py:266 does it as a second F.linear).
+// Not a translation of the mma.m16n8k16/ldmatrix/cp.async pipeline: the design follows the wave64 MFMA
+// operand maps.
+//
+// Forward  y[M,N] = x[M,K] . Wdeq[N,K]^T     (v_mfma_f32_32x32x16_f16, fp32 accumulate)
+//   * MFMA sums over k in any order as long as A and B agree.  The checkpoint's nibble order puts the
+//     k-pairs {2s+8j, 2s+8j+1 : j=0..3} of a 32-k chunk into u32 word s, so MFMA k-step s of chunk h uses
+//     word s as the B fragment of lane (n = lane&31, h = lane>>5) with NO shuffling: a lane loads the 16
+//     bytes of its (row n, chunk h) once per 64-k tile straight from HBM/L2 into VGPRs, dequantises in
+//     registers (bit-identical fp16 weights to the reference) and feeds 4 MFMA k-steps.  Weights never
+//     touch LDS.
+//   * The A operand (activations) is staged through LDS with the matching permutation applied for free
+//     while the registers are written out: dwords {s, s+4, s+8, s+12} of a 32-k chunk become 16-byte
+//     slot s, so every A fragment is one ds_read_b128.  Slots are XOR-swizzled with (row>>1)&7 so the
+//     16-lane ds_read_b128 groups hit 16 distinct 16-byte bank groups.
+//   * k-tiles inside the last n_out columns take their B fragments from the fp16 oweight slice instead
+//     of the (dead) nibbles: same MFMA stream, no second kernel, no read-modify-write of y.
+#include "qeft_common.h"
+
+namespace qeft {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+
+__device__ __forceinline__ int a_slot_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+struct BRegs {
+    u32x4 q[2];       // packed nibbles of (n, chunk h) for the two 32-column n-tiles
+    u32x4 o[2][4];    // fp16 outlier chunk (64 B) when the tile is in the outlier slice
+    f16 s[2], z[2];
+};
+
+template <bool OUTL>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
+                                                               const f16* __restrict__ scales,
+                                                               const f16* __restrict__ zeros,
+                                                               const f16* __restrict__ ow, const f16* __restrict__ bias,
+                                                               f16* __restrict__ y, int M, int N, int K, int G,
+                                                               int n_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BM * BK * 2];  // 2 x 16 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+    const int ktiles = K / BK;
+    const int kq = K - n_out;  // first outlier column
+
+    // A staging role: thread -> (row, 32-k chunk)
+    const int arow = tid >> 1, ach = tid & 1;
+    const bool arow_ok = bm0 + arow < M;
+    const f16* aptr = x + (size_t)(bm0 + arow) * K + ach * 32;
+
+    // B role: lane -> column n of two n-tiles, chunk h
+    int ncol[2];
+    bool nok[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        ncol[nt] = bn0 + wn * 64 + nt * 32 + r;
+        nok[nt] = ncol[nt] < N;
+        if (!nok[nt]) ncol[nt] = N - 1;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    u32x4 areg[4];
+    BRegs breg;
+
+    auto load_a = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            areg[j] = arow_ok ? ((const u32x4*)(aptr + (size_t)t * BK))[j] : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto store_a = [&](int buf) {
+        uint8_t* base = lds + buf * (BM * BK * 2);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // slot s of the chunk = dwords {s, s+4, s+8, s+12}
+            const u32x4 v = {areg[0][s], areg[1][s], areg[2][s], areg[3][s]};
+            *(u32x4*)(base + a_slot_off(arow, ach * 4 + s)) = v;
+        }
+    };
+    auto load_b = [&](int t, BRegs& b) {
+        const int k0 = t * BK + h * 32;
+        const bool outl = OUTL && k0 >= kq;
+        const int g = k0 / G;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = ncol[nt];
+            if (outl) {
+                const u32x4* p = (const u32x4*)(ow + (size_t)n * n_out + (k0 - kq));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b.o[nt][j] = p[j];
+            } else {
+                b.q[nt] = *(const u32x4*)(qw + (size_t)(n >> 2) * K * 2 + (size_t)t * 128 + (n & 3) * 32 + h * 16);
+                b.s[nt] = scales[(size_t)g * N + n];
+                b.z[nt] = zeros[(size_t)g * N + n];
+            }
+        }
+    };
+
+    load_a(0);
+    load_b(0, breg);
+    store_a(0);
+    __syncthreads();
+
+    for (int t = 0; t < ktiles; ++t) {
+        const int buf = t & 1;
+        BRegs bnext;
+        const bool more = t + 1 < ktiles;
+        if (more) {
+            load_a(t + 1);
+            load_b(t + 1, bnext);
+        }
+        const bool outl = OUTL && (t * BK + h * 32) >= kq;
+        const uint8_t* abase = lds + buf * (BM * BK * 2);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h8 bf[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                u32x4 bw;
+                if (outl) {
+                    bw = u32x4{breg.o[nt][0][s], breg.o[nt][1][s], breg.o[nt][2][s], breg.o[nt][3][s]};
+                } else {
+                    h2 wd[4];
+                    dequant8(breg.q[nt][s], splat(breg.s[nt]), splat(breg.z[nt]), wd);
+                    bw = u32x4{as_u32(wd[0]), as_u32(wd[1]), as_u32(wd[2]), as_u32(wd[3])};
+                }
+                bf[nt] = __builtin_bit_cast(h8, bw);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = wm * 64 + mt * 32 + r;
+                const h8 af = *(const h8*)(abase + a_slot_off(row, h * 4 + s));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_a(buf ^ 1);
+            breg = bnext;
+        }
+        __syncthreads();
+    }
+
+    // D map (32x32): col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        if (!nok[nt]) continue;
+        const int n = ncol[nt];
+        const float bv = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M) y[(size_t)m * N + n] = (f16)(acc[mt][nt][e] + bv);
+            }
+        }
+    }
+}
+
+hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
+                          const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st) {
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    if (ow && n_out > 0)
+        hipLaunchKernelGGL(gemm_w4_kernel<true>, grid, dim3(GEMM_THREADS), 0, st, (const f16*)x, (const uint8_t*)qw,
+                           (const f16*)scales, (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G,
+                           n_out);
+    else
+        hipLaunchKernelGGL(gemm_w4_kernel<false>, grid, dim3(GEMM_THREADS), 0, st, (const f16*)x, (const uint8_t*)qw,
+                           (const f16*)scales, (const f16*)zeros, (const f16*)nullptr, (const f16*)bias, (f16*)y, M, N,
+                           K, G, 0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward wrt input: dx[M,K] = dy[M,N] . Wdeq[N,K]  (contraction over n).
+// The contraction index is the packed layout's ROW index, so the weight tile is dequantised into LDS
+// transposed ([k][n], n contiguous) and both MFMA operands are read as 16-byte fragments in natural order.
+// Block tile: 128 (m) x 64 (k);  n advances 64 per stage.
+// ---------------------------------------------------------------------------------------------------
+constexpr int DX_BM = 128, DX_BK = 64, DX_BN = 64;
+constexpr int WT_STRIDE = DX_BN + 8;  // halves; 144-byte rows keep 16-byte alignment and spread banks
+
+__global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
+                                                         const f16* __restrict__ scales, const f16* __restrict__ zeros,
+                                                         const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
+                                                         int K, int G, int n_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_a[DX_BM * DX_BN * 2];        // dy tile [128][64], swizzled slots
+    __shared__ __attribute__((aligned(16))) f16 lds_w[DX_BK * WT_STRIDE];            // W^T tile [64 k][64 n (+8)]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wk = wave & 1;  // wave tile: 64 (m) x 32 (k)
+    const int bm0 = blockIdx.x * DX_BM, kt = blockIdx.y;  // kt: 64-k tile index
+    const int kq = K - n_out;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int arow = tid >> 1, ach = tid & 1;
+    const bool arow_ok = bm0 + arow < M;
+
+    // W staging role: thread -> (n_local = tid>>2, chunk = (tid>>1)&1, half = tid&1): 16 of the 32 k of a chunk
+    const int wn_l = tid >> 2, wch = (tid >> 1) & 1, whalf = tid & 1;
+
+    for (int n0 = 0; n0 < N; n0 += DX_BN) {
+        // ---- stage dy tile (natural k order inside each 32-chunk: slot s = dwords 4s..4s+3)
+        {
+            u32x4 v[4];
+            const f16* p = dy + (size_t)(bm0 + arow) * N + n0 + ach * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = arow_ok && (n0 + ach * 32 + j * 8) < N;
+                v[j] = ok ? ((const u32x4*)p)[j] : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(u32x4*)(lds_a + a_slot_off(arow, ach * 4 + j)) = v[j];
+        }
+        // ---- stage W^T tile
+        {
+            const int n = n0 + wn_l;
+            const int k0 = kt * 64 + wch * 32;
+            f16 vals[16];
+            if (n < N) {
+                if (ow != nullptr && k0 >= kq) {
+                    const f16* p = ow + (size_t)n * n_out + (k0 - kq) + whalf * 16;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) vals[e] = p[e];
+                } else {
+                    const u32x4 q = *(const u32x4*)(qw + (size_t)(n >> 2) * K * 2 + (size_t)kt * 128 + (n & 3) * 32 + wch * 16);
+                    const int g = k0 / G;
+                    const h2 s = splat(scales[(size_t)g * N + n]), z = splat(zeros[(size_t)g * N + n]);
+                    // this thread owns k_local = whalf*16 .. +15 of the chunk: dwords d = whalf*8 .. +7; dword d = w + 4j
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        h2 wd[4];
+                        dequant8(q[w], s, z, wd);
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = whalf * 2 + jj;          // dword w+4j covers k = 2w+8j, +1
+                            const int e = (w + 4 * j - whalf * 8) * 2;
+                            vals[e] = wd[j][0];
+                            vals[e + 1] = wd[j][1];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) vals[e] = (f16)0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) lds_w[(wch * 32 + whalf * 16 + e) * WT_STRIDE + wn_l] = vals[e];
+        }
+        __syncthreads();
+        // ---- MFMA: 4 n-steps of 16
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // B fragment: lane (k col = wk*32 + r, h): n = s*16 + 8h .. +7
+            const h8 bf = *(const h8*)(&lds_w[(wk * 32 + r) * WT_STRIDE + s * 16 + h * 8]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = wm * 64 + mt * 32 + r;
+                // A fragment: n = s*16 + 8h .. +7  -> chunk (s>>1), slot ((s&1)*2 + h)
+                const h8 af = *(const h8*)(lds_a + a_slot_off(row, (s >> 1) * 4 + (s & 1) * 2 + h));
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[mt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int kcol = kt * 64 + wk * 32 + r;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = bm0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < M) dx[(size_t)m * K + kcol] = (f16)acc[mt][e];
+        }
+}
+
+hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
+                             void* dx, int M, int N, int K, int G, int n_out, hipStream_t st) {
+    dim3 grid((M + DX_BM - 1) / DX_BM, K / DX_BK);
+    hipLaunchKernelGGL(gemm_w4_dx_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
+                       (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
+                       (f16*)dx, M, N, K, G, n_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// d_oweight[N, r] (fp32) = dy[M,N]^T . x[M, K-r:]   (qlinear.py:41-42).  Small (2*M*N*r flops); LDS-tiled
+// fp32 FMA kernel: block = 64 (n) x 64 (j) outputs, 16x16 threads x 4x4 each, m advances 16 per stage.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_oweight_kernel(const f16* __restrict__ dy, const f16* __restrict__ x,
+                                                           float* __restrict__ dow, int M, int N, int K, int R) {
+    __shared__ float sdy[16][64 + 1];
+    __shared__ float sx[16][64 + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int kq = K - R;
+    float acc[4][4] = {};
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+            const int mm = idx >> 6, c = idx & 63;
+            const int m = m0 + mm;
+            sdy[mm][c] = (m < M && n0 + c < N) ? (float)dy[(size_t)m * N + n0 + c] : 0.f;
+            sx[mm][c] = (m < M && j0 + c < R) ? (float)x[(size_t)m * K + kq + j0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sdy[mm][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sx[mm][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + ty * 4 + i, jj = j0 + tx * 4 + j;
+            if (n < N && jj < R) dow[(size_t)n * R + jj] = acc[i][j];
+        }
+}
+
+hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, int N, int K, int n_out,
+                               hipStream_t st) {
+    dim3 grid((N + 63) / 64, (n_out + 63) / 64);
+    hipLaunchKernelGGL(grad_oweight_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (float*)dow, M, N, K,
+                       n_out);
+    return hipGetLastError();
+}
+
+}  // namespace qeft

@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 W4 kernels.  HIP / CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qeft {
+
+typedef _Float16 f16;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ h2 as_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ h2 splat(f16 v) { return h2{v, v}; }
+
+// Checkpoint nibble order (qeft/qlinear.py:81-121, closed form in oracle.nibble_position):
+// the 16 bytes of one (row, 32-k chunk) are 4 u32 words; word w holds, in nibble i,
+//   i <  4 : k = 2w     + 8i
+//   i >= 4 : k = 2w + 1 + 8(i-4)
+// so masking with 0x000f000f / 0x00f000f0 (before and after >>8) yields the k-adjacent pairs
+//   out[j] = (k = 2w + 8j, k = 2w + 8j + 1),  j = 0..3
+// The integer -> fp16 conversion is the 0x6400 exponent trick the reference uses
+// (dequantize.cuh:14-77): 0x6400|q == 1024+q, 0x6400|(q<<4) == 1024+16q; both are
+// brought back to q exactly, then ONE rounded fp16 FMA q*s+sz gives the same fp16
+// weight as the reference's __hfma2 (gemv_cuda_qeft.cu:158, gemm_cuda.cu:280-286).
+__device__ __forceinline__ void nib8_to_q(uint32_t v, h2 (&q)[4]) {
+    const uint32_t MAGIC = 0x64006400u;
+    const h2 k1024 = {(f16)1024.f, (f16)1024.f};
+    const h2 k16th = {(f16)0.0625f, (f16)0.0625f};
+    const h2 kn64 = {(f16)-64.f, (f16)-64.f};
+    const uint32_t t = v >> 8;
+    q[0] = as_h2((v & 0x000f000fu) | MAGIC) - k1024;
+    q[1] = __builtin_elementwise_fma(as_h2((v & 0x00f000f0u) | MAGIC), k16th, kn64);
+    q[2] = as_h2((t & 0x000f000fu) | MAGIC) - k1024;
+    q[3] = __builtin_elementwise_fma(as_h2((t & 0x00f000f0u) | MAGIC), k16th, kn64);
+}
+
+__device__ __forceinline__ void dequant8(uint32_t v, h2 s, h2 z, h2 (&w)[4]) {
+    h2 q[4];
+    nib8_to_q(v, q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __builtin_elementwise_fma(q[j], s, z);
+}
+
+// Arguments of the decode GEMV (gemv_w4.hip); built by the C ABI (capi.hip).
+struct GemvArgs {
+    const f16* x;
+    const uint8_t* qw;
+    const f16* scales;
+    const f16* zeros;
+    const f16* ow_il;
+    const f16* bias;
+    const int* ids;
+    const f16* residual;
+    f16* y;
+    int N, K, G, n_out;
+};
+
+__device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+
+}  // namespace qeft

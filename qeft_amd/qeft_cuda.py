@@ -1,0 +1,176 @@
+"""Python operator module with the reference extension's surface (`import qeft_cuda`).
+
+Mirrors the functions the reference binds in qeft/kernel/qeft_cuda.cpp:10-27 for the quantized
+linear — same names, positional arguments and error behaviour — implemented by ctypes calls into
+the gfx950 C ABI (include/qeft_hip.h).  Outputs are freshly allocated on the input's device with
+the input's dtype (gemv_cuda_qeft.cu:404-414, gemm_cuda.cu:935-950).  Unlike the reference the
+kernels are launched on torch's *current* stream of the input's device, and shapes / dtypes /
+contiguity are validated (the reference validates nothing).
+"""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_common(in_feats, kernel, scales, zeros):
+    _need(in_feats.is_cuda, "in_feats must be a GPU tensor (no CPU fallback)")
+    _need(in_feats.dtype == torch.float16, "expected scalar type Half for in_feats")
+    _need(kernel.dtype == torch.int16, "expected scalar type Short for kernel")
+    _need(scales.dtype == torch.float16 and zeros.dtype == torch.float16, "expected scalar type Half for scales/zeros")
+    for t, n in ((kernel, "kernel"), (scales, "scales"), (zeros, "zeros")):
+        _need(t.device == in_feats.device, f"{n} is on {t.device}, in_feats on {in_feats.device}")
+        _need(t.is_contiguous(), f"{n} must be contiguous")
+
+
+def gemv_4bit(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size):
+    """gemv_cuda.cu:358-525.  m in 1..7 else RuntimeError("Unsupported batch size for gemv kernel.")."""
+    _check_common(in_feats, kernel, scaling_factors, zeros)
+    x = in_feats.contiguous()
+    _need(x.numel() == m * k, f"in_feats has {x.numel()} elements, expected m*k = {m * k}")
+    _need(kernel.shape == (n // 4, k), f"kernel shape {tuple(kernel.shape)} != ({n // 4}, {k})")
+    out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+    with torch.cuda.device(in_feats.device):
+        _lib.check(_lib.lib().qeft_gemv_w4(x.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(),
+                                           zeros.data_ptr(), out.data_ptr(), m, n, k, group_size, _stream(x)))
+    return out
+
+
+def gemv_4bit_qeft(in_feats, kernel, scaling_factors, zeros, oweight, m, n, k, group_size):
+    """gemv_cuda_qeft.cu:392-513.  `oweight` is the interleaved [N/2, 2r] buffer; r = oweight.size(1)/2 (:424)."""
+    _check_common(in_feats, kernel, scaling_factors, zeros)
+    _need(oweight.dtype == torch.float16 and oweight.is_contiguous() and oweight.device == in_feats.device,
+          "oweight_interleaved must be a contiguous Half tensor on the input's device")
+    x = in_feats.contiguous()
+    _need(x.numel() == m * k, f"in_feats has {x.numel()} elements, expected m*k = {m * k}")
+    _need(kernel.shape == (n // 4, k), f"kernel shape {tuple(kernel.shape)} != ({n // 4}, {k})")
+    n_out = oweight.shape[1] // 2
+    _need(oweight.shape[0] == n // 2, f"oweight_interleaved has {oweight.shape[0]} rows, expected {n // 2}")
+    out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+    with torch.cuda.device(in_feats.device):
+        _lib.check(_lib.lib().qeft_gemv_w4_qeft(x.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(),
+                                                zeros.data_ptr(), oweight.data_ptr(), out.data_ptr(), m, n, k,
+                                                group_size, n_out, _stream(x)))
+    return out
+
+
+def gemm_4bit(in_feats, kernel, scales, zeros):
+    """gemm_cuda.cu:929-1033: N = kernel.size(0)*4 (:936), M = numel/K (:937); every column from the nibbles."""
+    return gemm_4bit_qeft(in_feats, kernel, scales, zeros, None)
+
+
+def gemm_4bit_qeft(in_feats, kernel, scales, zeros, oweights, bias=None):
+    """The fused GEMM gemm_cuda_qeft.cu:1003 declared but never shipped: the last r = oweights.size(1) input
+    columns come from the plain fp16 `oweights` [N, r] inside the same launch (qlinear.py:266 adds them with a
+    second F.linear).  oweights=None gives gemm_4bit.  Extension: optional fused bias."""
+    _check_common(in_feats, kernel, scales, zeros)
+    x = in_feats.contiguous()
+    k = x.shape[-1]
+    n = kernel.shape[0] * 4
+    m = x.numel() // k
+    _need(kernel.shape[1] == k, f"kernel has K={kernel.shape[1]}, in_feats has K={k}")
+    group = k // scales.shape[0]
+    n_out = 0
+    if oweights is not None:
+        _need(oweights.dtype == torch.float16 and oweights.is_contiguous() and oweights.shape[0] == n,
+              "oweights must be a contiguous Half [N, r] tensor")
+        n_out = oweights.shape[1]
+    out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(in_feats.device):
+        _lib.check(_lib.lib().qeft_gemm_w4(x.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                           oweights.data_ptr() if n_out else None,
+                                           bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k,
+                                           group, n_out, _stream(x)))
+    return out
+
+
+# ---- entry points beyond the reference's module (used by QuantLinear's fused paths and the backward) ----
+
+def gemv_4bit_fused(in_feats, kernel, scaling_factors, zeros, oweight_il, bias, reorder_ids, residual, m, n, k,
+                    group_size):
+    """One launch for everything QuantLinear.forward_* does around the GEMV (qlinear.py:244-330)."""
+    _check_common(in_feats, kernel, scaling_factors, zeros)
+    x = in_feats.contiguous()
+    _need(x.numel() == m * k, f"in_feats has {x.numel()} elements, expected m*k = {m * k}")
+    n_out = oweight_il.shape[1] // 2 if oweight_il is not None else 0
+    if reorder_ids is not None:
+        _need(reorder_ids.dtype == torch.int32 and reorder_ids.numel() == k and reorder_ids.is_contiguous(),
+              "reorder_ids must be a contiguous int32 [K] tensor")
+    if residual is not None:
+        residual = residual.contiguous()
+        _need(residual.numel() == m * n and residual.dtype == torch.float16, "residual must be Half [m, N]")
+    out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+    with torch.cuda.device(in_feats.device):
+        _lib.check(_lib.lib().qeft_gemv_w4_fused(
+            x.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
+            oweight_il.data_ptr() if n_out else None, bias.data_ptr() if bias is not None else None,
+            reorder_ids.data_ptr() if reorder_ids is not None else None,
+            residual.data_ptr() if residual is not None else None, out.data_ptr(), m, n, k, group_size, n_out,
+            _stream(x)))
+    return out
+
+
+def gemm_4bit_dx(grad_out, kernel, scales, zeros, oweights):
+    """dX[M,K] = dY[M,N] . Wdeq[N,K] with the outlier columns taken from oweights."""
+    _check_common(grad_out, kernel, scales, zeros)
+    dy = grad_out.contiguous()
+    n = kernel.shape[0] * 4
+    k = kernel.shape[1]
+    m = dy.numel() // n
+    _need(dy.shape[-1] == n, f"grad_out has N={dy.shape[-1]}, kernel has N={n}")
+    group = k // scales.shape[0]
+    n_out = oweights.shape[1] if oweights is not None else 0
+    out = torch.empty(*grad_out.shape[:-1], k, dtype=grad_out.dtype, device=grad_out.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.lib().qeft_gemm_w4_dx(dy.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                              oweights.data_ptr() if n_out else None, out.data_ptr(), m, n, k, group,
+                                              n_out, _stream(dy)))
+    return out
+
+
+def grad_oweight(grad_out, in_feats, n_out):
+    """d_oweight[N, r] (fp32) = dY^T . x[..., K-r:]  (qlinear.py:41-42)."""
+    dy = grad_out.contiguous()
+    x = in_feats.contiguous()
+    _need(dy.dtype == torch.float16 and x.dtype == torch.float16, "expected Half tensors")
+    n, k = dy.shape[-1], x.shape[-1]
+    m = dy.numel() // n
+    _need(x.numel() // k == m, "grad_out and in_feats disagree on the number of tokens")
+    out = torch.empty(n, n_out, dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.lib().qeft_grad_oweight(dy.data_ptr(), x.data_ptr(), out.data_ptr(), m, n, k, n_out,
+                                                _stream(dy)))
+    return out
+
+
+def dequantize_weight_4bit_qeft(kernel, scales, zeros, oweights=None):
+    """Dense fp16 Wdeq[N, K] (role of the reference's uncompiled dequantize_weight_4bit_qeft, qeft_cuda.cpp:14)."""
+    n, k = kernel.shape[0] * 4, kernel.shape[1]
+    group = k // scales.shape[0]
+    n_out = oweights.shape[1] if oweights is not None else 0
+    out = torch.empty(n, k, dtype=torch.float16, device=kernel.device)
+    with torch.cuda.device(kernel.device):
+        _lib.check(_lib.lib().qeft_dequant_w4(kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                              oweights.data_ptr() if n_out else None, out.data_ptr(), n, k, group,
+                                              n_out, _stream(kernel)))
+    return out
+
+
+def pack_oweight_device(oweights):
+    """oweight [N, r] -> oweight_interleaved [N/2, 2r] on device (pack_oweight, qlinear.py:70-79)."""
+    ow = oweights.contiguous()
+    n, r = ow.shape
+    out = torch.empty(n // 2, 2 * r, dtype=ow.dtype, device=ow.device)
+    with torch.cuda.device(ow.device):
+        _lib.check(_lib.lib().qeft_pack_oweight(ow.data_ptr(), out.data_ptr(), n, r, _stream(ow)))
+    return out

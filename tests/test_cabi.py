@@ -1,0 +1,85 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol that
+include/qeft_hip.h declares; argument validation that needs no GPU; the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from qeft_amd import _lib, build
+    build.build(verbose=False)
+    return _lib.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "qeft_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qeft_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 11
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/qeft_hip.h but not exported"
+    from qeft_amd import _lib
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.qeft_abi_version() == 1
+    assert lib.qeft_error_string(1).decode() == "Unsupported batch size for gemv kernel."
+    assert lib.qeft_error_string(0).decode() == "ok"
+
+
+def test_argument_validation_without_gpu(lib):
+    """Validation happens before any HIP call, so these run on a GPU-less host."""
+    buf = ctypes.create_string_buffer(4096 + 16)
+    p = (ctypes.addressof(buf) + 15) & ~15
+    g = lib.qeft_gemv_w4
+    assert g(p, p, p, p, p, 8, 64, 512, 128, None) == 1       # batch
+    assert g(p, p, p, p, p, 0, 64, 512, 128, None) == 1
+    assert g(p, p, p, p, p, 1, 62, 512, 128, None) == 2       # N % 4
+    assert g(p, p, p, p, p, 1, 64, 500, 128, None) == 2       # K % 64
+    assert g(p, p, p, p, p, 1, 64, 512, 48, None) == 3        # group
+    assert g(None, p, p, p, p, 1, 64, 512, 128, None) == 4    # null
+    assert g(p + 2, p, p, p, p, 1, 64, 512, 128, None) == 6   # alignment
+    q = lib.qeft_gemv_w4_qeft
+    assert q(p, p, p, p, None, p, 1, 64, 512, 128, 128, None) == 4
+    assert q(p, p, p, p, p, p, 1, 64, 512, 128, 100, None) == 2
+    assert q(p, p, p, p, p, p, 1, 60, 512, 128, 128, None) == 2   # outliers need N % 8
+    assert lib.qeft_gemm_w4(p, p, p, p, None, None, p, 0, 64, 512, 128, 0, None) == 2
+
+
+def test_no_cpu_fallback():
+    """A CPU tensor must raise, never silently compute on the host."""
+    from qeft_amd import qeft_cuda
+    x = torch.zeros(1, 128, dtype=torch.float16)
+    qw = torch.zeros(2, 128, dtype=torch.int16)
+    s = torch.zeros(1, 8, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        qeft_cuda.gemv_4bit(x, qw, s, s, 1, 8, 128, 128)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        qeft_cuda.gemm_4bit(x, qw, s, s)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from qeft_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libqeft_hip.so")
+    with pytest.raises(_lib.QeftHipError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_does_not_import_oracle():
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "qeft_amd", "**", "*.py"), recursive=True) + \
+            [os.path.join(ROOT, "qeft_cuda.py")]:
+        src = open(path).read()
+        assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{path} references the oracle"

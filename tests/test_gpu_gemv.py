@@ -1,0 +1,121 @@
+"""GPU parity: decode GEMV (C ABI via the qeft_cuda shim) vs the CPU oracle.  fp16 tolerance 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import qeft_oracle as O
+from util import REL_TOL, elem_err_ok, layer_to_torch, oracle_forward, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def run_case(n, k, r, g, m, seed, bias=False, gather=False, residual=False, fused=True):
+    from qeft_amd import qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=seed, bias=bias)
+    x = O.make_activation(m, k, r, seed=seed)
+    t = layer_to_torch(bufs, DEV)
+    xt = torch.from_numpy(x).to(DEV)
+    ids = None
+    if gather:
+        rng = np.random.default_rng(seed)
+        out_idx = np.sort(rng.choice(k, size=max(r, 1), replace=False))
+        ids = O.sparse_to_dense_ids(out_idx, k)
+    res = None
+    if residual:
+        res = (np.random.default_rng(seed + 5).standard_normal((m, n)) * 0.5).astype(np.float16)
+    yref = oracle_forward(bufs, x, r, g, reorder_ids=ids).astype(np.float64)
+    if res is not None:
+        yref = (yref + res.astype(np.float64))
+    if fused:
+        y = qeft_cuda.gemv_4bit_fused(xt, t["qweight"], t["scales"], t["scaled_zeros"],
+                                      t.get("oweight_interleaved") if r else None, t.get("bias"),
+                                      torch.from_numpy(ids.astype(np.int32)).to(DEV) if ids is not None else None,
+                                      torch.from_numpy(res).to(DEV) if res is not None else None, m, n, k, g)
+    elif r:
+        y = qeft_cuda.gemv_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"],
+                                     m, n, k, g)
+    else:
+        y = qeft_cuda.gemv_4bit(xt, t["qweight"], t["scales"], t["scaled_zeros"], m, n, k, g)
+    torch.cuda.synchronize()
+    y = y.cpu().numpy()
+    assert y.shape == (m, n) and y.dtype == np.float16
+    assert rel_err(y, yref) < REL_TOL, (rel_err(y, yref), n, k, r, g, m)
+    assert elem_err_ok(y, yref)
+    return y
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6, 7])
+def test_gemv_qeft_small_batches(m):
+    run_case(256, 1024, 128, 128, m, seed=m, fused=False)
+
+
+@pytest.mark.parametrize("m", [1, 4, 7])
+def test_gemv_plain_no_outliers(m):
+    run_case(256, 1024, 0, 128, m, seed=10 + m, fused=False)
+
+
+@pytest.mark.parametrize("n,k,r,g", [
+    (8, 128, 0, 128), (8, 128, 64, 64), (16, 256, 128, 128), (64, 512, 64, 128), (24, 384, 0, 128),
+    (40, 576, 32, 64), (512, 4096, 128, 128), (1376, 4096, 128, 128), (512, 11008, 128, 128),
+    (64, 2048, 128, 2048),  # per-channel (group == K)
+    (128, 640, 96, 32),
+])
+def test_gemv_shapes_and_groups(n, k, r, g):
+    run_case(n, k, r, g, 1, seed=n + k)
+    run_case(n, k, r, g, 3, seed=n + k + 1)
+
+
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008), (5120, 5120), (13824, 5120),
+                                 (5120, 13824)])
+def test_gemv_llama_shapes(n, k):
+    run_case(n, k, 128, 128, 1, seed=7)
+
+
+def test_gemv_fused_bias_gather_residual():
+    run_case(256, 1024, 128, 128, 1, seed=3, bias=True)
+    run_case(256, 1024, 128, 128, 2, seed=4, bias=True, gather=True)
+    run_case(512, 4096, 128, 128, 1, seed=5, gather=True, residual=True)
+    run_case(256, 1024, 0, 128, 5, seed=6, bias=True, gather=True, residual=True)
+
+
+def test_gemv_batch_out_of_range_raises():
+    """m outside 1..7 -> RuntimeError with the reference's message (gemv_cuda_qeft.cu:466)."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(64, 512, 128, 128, seed=0)
+    t = layer_to_torch(bufs, DEV)
+    for m in (8, 9):
+        x = torch.zeros(m, 512, dtype=torch.float16, device=DEV)
+        with pytest.raises(RuntimeError, match="Unsupported batch size for gemv kernel"):
+            qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"],
+                                     m, 64, 512, 128)
+        with pytest.raises(RuntimeError, match="Unsupported batch size for gemv kernel"):
+            qeft_cuda.gemv_4bit(x, t["qweight"], t["scales"], t["scaled_zeros"], m, 64, 512, 128)
+    x = torch.zeros(1, 512, dtype=torch.float16, device=DEV)
+    code = _lib.lib().qeft_gemv_w4(x.data_ptr(), t["qweight"].data_ptr(), t["scales"].data_ptr(),
+                                   t["scaled_zeros"].data_ptr(), x.data_ptr(), 0, 64, 512, 128, None)
+    assert code == 1
+
+
+def test_gemv_rows_are_independent_of_sharding():
+    """N-sharding property: a row's result does not depend on which rows share its launch,
+    as long as the block shape (rows per block) is the same -> shard outputs concatenate bit-exactly."""
+    from qeft_amd import qeft_cuda
+    n, k, r, g = 2048, 4096, 128, 128
+    bufs = O.make_layer(n, k, r, g, seed=11)
+    x = torch.from_numpy(O.make_activation(1, k, r, seed=11)).to(DEV)
+    t = layer_to_torch(bufs, DEV)
+    full = qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"],
+                                    1, n, k, g)
+    parts = []
+    for s in range(2):
+        n0, n1 = s * n // 2, (s + 1) * n // 2
+        parts.append(qeft_cuda.gemv_4bit_qeft(
+            x, t["qweight"][n0 // 4:n1 // 4].contiguous(), t["scales"][:, n0:n1].contiguous(),
+            t["scaled_zeros"][:, n0:n1].contiguous(), t["oweight_interleaved"][n0 // 2:n1 // 2].contiguous(),
+            1, n1 - n0, k, g))
+    torch.cuda.synchronize()
+    got = torch.cat(parts, dim=-1)
+    # fp32 sums are order-dependent only through the block shape; allow 1 fp16 ulp
+    assert rel_err(got.cpu().numpy(), full.cpu().numpy()) < 1e-3
