@@ -62,7 +62,6 @@ int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, c
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight_il))) return QEFT_ERR_ALIGN;
-    if (reorder_ids && (size_t)m * k * 2 + 4096 > 160 * 1024) return QEFT_ERR_SHAPE;
     qeft::GemvArgs a;
     a.x = (const qeft::f16*)x;
     a.qw = (const uint8_t*)qweight;
@@ -77,6 +76,8 @@ int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, c
     a.K = k;
     a.G = group_size;
     a.n_out = n_out;
+    if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
+    a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
     return finish(qeft::gemv_w4_dispatch(a, m, (hipStream_t)stream));
 }
 

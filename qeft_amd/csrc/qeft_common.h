@@ -59,6 +59,7 @@ struct GemvArgs {
     const f16* residual;
     f16* y;
     int N, K, G, n_out;
+    int gshift;  // log2(G) for power-of-two groups, 31 when G == K (single group)
 };
 
 __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }

@@ -37,9 +37,8 @@ def main():
             ws.append((qw, sc, sz, ow))
         x = torch.randn(m, k, device=dev).half()
         y = torch.empty(m, n, device=dev, dtype=torch.float16)
-        st = torch.cuda.current_stream().cuda_stream
-
         def run_all():
+            st = torch.cuda.current_stream().cuda_stream
             for qw, sc, sz, ow in ws:
                 lib.qeft_gemv_w4_qeft(x.data_ptr(), qw.data_ptr(), sc.data_ptr(), sz.data_ptr(), ow.data_ptr(),
                                       y.data_ptr(), m, n, k, g, r, st)
