@@ -95,6 +95,30 @@ int qeft_dequant_w4(const void* qweight, const void* scales, const void* scaled_
  * used after fine-tuning so the GEMV never reads a stale copy (modelutils.py:192 quirk). */
 int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, qeft_stream_t stream);
 
+/* ---- decode-step helpers (SURVEY.md section 8f "next" rows 1, 3, 4; not part of the packed-weight path) ---- */
+
+/* Up to 3 quantized linears that read the SAME x (q/k/v or gate/up) in one launch, batch 1.
+ * Host arrays of `nparts` device pointers; oweight_il / bias entries may be NULL (all-or-none for oweight_il).
+ * Equivalent to nparts calls of gemv_4bit_qeft (gemv_cuda_qeft.cu:392-513) on identical in_feats. */
+int qeft_gemv_w4_group(const void* x, int nparts, const void* const* qweight, const void* const* scales,
+                       const void* const* scaled_zeros, const void* const* oweight_il, const void* const* bias,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream);
+
+/* y = rmsnorm(x (+ add)) * gamma, fp32 statistics (role of layernorm_forward_cuda, qeft/kernel/layernorm/layernorm.cu:26-76).
+ * If add != NULL the sum x + add is normalised and, if res_out != NULL, also written there (fused residual). */
+int qeft_rmsnorm(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int hidden,
+                 float eps, qeft_stream_t stream);
+
+/* out = silu(gate) * up, n elements (n % 8 == 0). */
+int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_stream_t stream);
+
+/* One decode token of one sequence: rotary on q/k at position *pos (device int), append k/v to the caches
+ * [n_kv][max_seq][128] and compute softmax(q.K^T/sqrt(128)).V (role of single_query_attention,
+ * qeft/kernel/attention/ft_attention.cpp:110-181, neox rotary).  head_dim is 128. cos/sin: fp32 [max_seq][64]. */
+int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                          void* k_cache, void* v_cache, const int* pos, void* out, int n_heads, int n_kv_heads,
+                          int max_seq, qeft_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

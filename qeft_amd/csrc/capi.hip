@@ -7,6 +7,13 @@
 
 namespace qeft {
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
+hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
+hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int H,
+                          float eps, hipStream_t st);
+hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
+hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
+                                   void* vc, const int* pos, void* out, int n_heads, int n_kv, int max_seq,
+                                   hipStream_t st);
 hipError_t dequant_w4_launch(const void* qw, const void* scales, const void* zeros, const void* ow, void* out, int N,
                              int K, int G, int n_out, hipStream_t st);
 hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream_t st);
@@ -112,6 +119,7 @@ int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, con
     if (m < 1) return QEFT_ERR_SHAPE;
     if (!oweight) n_out = 0;
     if (int e = check_common(n, k, group_size, n_out)) return e;
+    if (n % 8 != 0) return QEFT_ERR_SHAPE;  // dy rows are read 16 bytes at a time
     if (!dy || !qweight || !scales || !scaled_zeros || !dx) return QEFT_ERR_NULL;
     if (!aligned16(dy) || !aligned16(qweight) || !aligned16(dx) || (n_out > 0 && !aligned16(oweight)))
         return QEFT_ERR_ALIGN;
@@ -140,6 +148,61 @@ int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, q
     if (n <= 0 || n % 8 != 0 || n_out <= 0 || n_out % 32 != 0) return QEFT_ERR_SHAPE;
     if (!oweight || !oweight_il) return QEFT_ERR_NULL;
     return finish(qeft::pack_oweight_launch(oweight, oweight_il, n, n_out, (hipStream_t)stream));
+}
+
+int qeft_gemv_w4_group(const void* x, int nparts, const void* const* qweight, const void* const* scales,
+                       const void* const* scaled_zeros, const void* const* oweight_il, const void* const* bias,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    if (nparts < 1 || nparts > 3) return QEFT_ERR_SHAPE;
+    if (!x || !qweight || !scales || !scaled_zeros || !y || !n) return QEFT_ERR_NULL;
+    if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;
+    qeft::GemvGroupArgs g{};
+    g.x = (const qeft::f16*)x;
+    for (int p = 0; p < nparts; ++p) {
+        if (int e = check_common(n[p], k, group_size, n_out)) return e;
+        if (!qweight[p] || !scales[p] || !scaled_zeros[p] || !y[p] || (n_out > 0 && (!oweight_il || !oweight_il[p])))
+            return QEFT_ERR_NULL;
+        if (!aligned16(qweight[p]) || (n_out > 0 && !aligned16(oweight_il[p]))) return QEFT_ERR_ALIGN;
+        g.qw[p] = (const uint8_t*)qweight[p];
+        g.scales[p] = (const qeft::f16*)scales[p];
+        g.zeros[p] = (const qeft::f16*)scaled_zeros[p];
+        g.ow_il[p] = n_out > 0 ? (const qeft::f16*)oweight_il[p] : nullptr;
+        g.bias[p] = bias ? (const qeft::f16*)bias[p] : nullptr;
+        g.y[p] = (qeft::f16*)y[p];
+        g.N[p] = n[p];
+    }
+    if (!aligned16(x)) return QEFT_ERR_ALIGN;
+    g.K = k;
+    g.G = group_size;
+    g.n_out = n_out;
+    g.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
+    return finish(qeft::gemv_w4_group_dispatch(g, nparts, (hipStream_t)stream));
+}
+
+int qeft_rmsnorm(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int hidden,
+                 float eps, qeft_stream_t stream) {
+    if (m < 1 || hidden < 8 || hidden % 8 != 0) return QEFT_ERR_SHAPE;
+    if (!x || !gamma || !y) return QEFT_ERR_NULL;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || (add && !aligned16(add)) || (res_out && !aligned16(res_out)))
+        return QEFT_ERR_ALIGN;
+    return finish(qeft::rmsnorm_launch(x, add, gamma, res_out, y, m, hidden, eps, (hipStream_t)stream));
+}
+
+int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_stream_t stream) {
+    if (n < 8 || n % 8 != 0) return QEFT_ERR_SHAPE;
+    if (!gate || !up || !out) return QEFT_ERR_NULL;
+    if (!aligned16(gate) || !aligned16(up) || !aligned16(out)) return QEFT_ERR_ALIGN;
+    return finish(qeft::silu_mul_launch(gate, up, out, n, (hipStream_t)stream));
+}
+
+int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                          void* k_cache, void* v_cache, const int* pos, void* out, int n_heads, int n_kv_heads,
+                          int max_seq, qeft_stream_t stream) {
+    if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || max_seq < 1 || max_seq > 32768) return QEFT_ERR_SHAPE;
+    if (!q || !k || !v || !cos_tab || !sin_tab || !k_cache || !v_cache || !pos || !out) return QEFT_ERR_NULL;
+    if (!aligned16(k_cache) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
+    return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache, v_cache, pos, out, n_heads,
+                                                n_kv_heads, max_seq, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -93,4 +93,39 @@ hipError_t gemv_w4_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
     return hipSuccess;
 }
 
+// ---- grouped launch (decode engine): up to 3 linears sharing x, batch 1
+template <int RGI, int D>
+static hipError_t launch_group(const GemvGroupArgs& g, int nblocks, hipStream_t st) {
+    const size_t smem = gemv_smem_bytes(kNW, RGI, 1, g.K, g.G, g.n_out);
+    if (g.n_out > 0)
+        hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, true>), dim3(nblocks), dim3(kNW * 64), smem, st, g);
+    else
+        hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, false>), dim3(nblocks), dim3(kNW * 64), smem, st, g);
+    return hipGetLastError();
+}
+
+hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st) {
+    int total_rgs = 0;
+    for (int p = 0; p < nparts; ++p) total_rgs += g.N[p] / 4;
+    int rgi = 4;
+    for (;;) {
+        bool ok = total_rgs / rgi >= 256 || rgi == 1;
+        for (int p = 0; p < nparts; ++p) ok = ok && ((g.N[p] / 4) % rgi == 0);
+        if (ok || rgi == 1) break;
+        rgi >>= 1;
+    }
+    int acc = 0;
+    for (int p = 0; p < 3; ++p) {
+        if (p < nparts) acc += g.N[p] / (4 * rgi);
+        g.blk_end[p] = acc;
+    }
+    if (gemv_smem_bytes(kNW, rgi, 1, g.K, g.G, g.n_out) > 64 * 1024) return hipErrorInvalidValue;
+    const bool deep = g.K > 6144;
+    switch (rgi) {
+        case 4: return deep ? launch_group<4, 4>(g, acc, st) : launch_group<4, 2>(g, acc, st);
+        case 2: return deep ? launch_group<2, 4>(g, acc, st) : launch_group<2, 2>(g, acc, st);
+        default: return deep ? launch_group<1, 4>(g, acc, st) : launch_group<1, 2>(g, acc, st);
+    }
+}
+
 }  // namespace qeft

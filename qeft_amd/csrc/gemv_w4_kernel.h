@@ -40,7 +40,7 @@ __host__ __device__ constexpr size_t gemv_smem_bytes(int NW, int RGI, int M, int
 // 5 integer ops + 4 dot2 per 8 weights instead of 13 + 4; weights are the exact q*s+sz (not rounded to fp16).
 // NW   waves per block (4 or 8); wave w owns the steps w, w+NW, ...
 template <int NW, int RGI, int M, int D, bool OUTL, bool XG, int ABL = 0>
-__global__ __launch_bounds__(NW * 64) void gemv_w4_kernel(GemvArgs a) {
+__device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
     constexpr int kWaves = NW, kBlock = NW * 64;
     constexpr int LPS = 64 / RGI;        // lanes per row-group within the wave
     constexpr int KSTEP = 512 / RGI;     // k advanced per step
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_kernel(GemvArgs a) {
     const int sub = lane / LPS, lin = lane % LPS;
     const int r = (lane >> 1) & 3;
     const int koff = (lin >> 3) * 64 + (lane & 1) * 32;
-    const int rg0 = blockIdx.x * RGI;
+    const int rg0 = blk * RGI;
     const int rg = rg0 + sub;
     const int row = rg * 4 + r;
     const int kq = a.K - (OUTL ? a.n_out : 0);      // INT4 columns [0, kq), fp16 outlier slice [kq, K)
@@ -100,7 +100,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_kernel(GemvArgs a) {
     const uint8_t* wbase = a.qw + (size_t)rg * a.K * 2;
     auto issue = [&](RingSlot& b, int s) {
         s = min(s, s_last);                              // past the wave's last step: harmless re-read of it
-        b.w = __builtin_nontemporal_load((const u32x4*)(wbase + (uint32_t)s * (1024 / RGI) + lin * 16));
+        // clamp inside the row-group: a wave without ring steps (K < one step) still issues its (unused) loads
+        const uint32_t woff = min((uint32_t)s * (1024 / RGI) + lin * 16, (uint32_t)a.K * 2 - 16);
+        b.w = __builtin_nontemporal_load((const u32x4*)(wbase + woff));
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -305,6 +307,35 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_kernel(GemvArgs a) {
         if (a.residual) v += (float)a.residual[(size_t)bm * a.N + orow];
         a.y[(size_t)bm * a.N + orow] = (f16)v;
     }
+}
+
+template <int NW, int RGI, int M, int D, bool OUTL, bool XG, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void gemv_w4_kernel(GemvArgs a) {
+    gemv_w4_body<NW, RGI, M, D, OUTL, XG, ABL>(a, blockIdx.x);
+}
+
+// Several linears that share the same input (q/k/v, gate/up) in ONE launch: block ranges [blk_end[p-1], blk_end[p])
+// belong to part p.  Same K / group / n_out / batch for all parts; N may differ.
+template <int NW, int RGI, int M, int D, bool OUTL>
+__global__ __launch_bounds__(NW * 64) void gemv_w4_group_kernel(GemvGroupArgs g) {
+    int p = 0, blk = blockIdx.x;
+    if (blk >= g.blk_end[0]) { p = 1; blk -= g.blk_end[0]; if (blockIdx.x >= (unsigned)g.blk_end[1]) { p = 2; blk = blockIdx.x - g.blk_end[1]; } }
+    GemvArgs a;
+    a.x = g.x;
+    a.qw = g.qw[p];
+    a.scales = g.scales[p];
+    a.zeros = g.zeros[p];
+    a.ow_il = g.ow_il[p];
+    a.bias = g.bias[p];
+    a.ids = nullptr;
+    a.residual = nullptr;
+    a.y = g.y[p];
+    a.N = g.N[p];
+    a.K = g.K;
+    a.G = g.G;
+    a.n_out = g.n_out;
+    a.gshift = g.gshift;
+    gemv_w4_body<NW, RGI, M, D, OUTL, false, 0>(a, blk);
 }
 
 }  // namespace qeft

@@ -62,6 +62,19 @@ struct GemvArgs {
     int gshift;  // log2(G) for power-of-two groups, 31 when G == K (single group)
 };
 
+struct GemvGroupArgs {
+    const f16* x;
+    const uint8_t* qw[3];
+    const f16* scales[3];
+    const f16* zeros[3];
+    const f16* ow_il[3];
+    const f16* bias[3];
+    f16* y[3];
+    int N[3];
+    int blk_end[3];
+    int K, G, n_out, gshift;
+};
+
 __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 
 }  // namespace qeft

@@ -1,0 +1,325 @@
+"""Self-contained Llama-shaped decode harness around QuantLinear.
+
+The reference measures decode speed by driving HF `LlamaForCausalLM` token by token (qeft/main.py:310-371,
+qeft/benchmark.py:293-338).  HF model loading needs the hub, so the harness builds its own Llama-2-shaped module
+tree (same attribute names as HF: model.layers[i].self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj) with
+synthetic packed weights, and a `DecodeEngine` that runs one token as a fixed sequence of
+C-ABI launches on static buffers so the whole step can be captured into one hipGraph:
+
+    rmsnorm -> [q|k|v] grouped GEMV -> rotary + KV append + attention -> o_proj GEMV (+gather, +residual)
+            -> rmsnorm -> [gate|up] grouped GEMV -> silu*mul -> down_proj GEMV (+residual)
+
+`QuantLlama.forward_dense_reference` is a plain fp32 PyTorch implementation over the dense dequantised weights,
+used by the tests and by `eval_nll` as the parity target ("PPL vs reference" on synthetic weights).
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .qlinear import QuantLinear
+from .quant import fake_quantize, minmax_params
+
+
+@dataclass
+class LlamaShape:
+    hidden: int
+    inter: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    vocab: int
+    max_seq: int = 512
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    n_out: int = 128
+    group_size: int = 128
+    name: str = "llama"
+
+    @property
+    def head_dim(self):
+        return self.hidden // self.n_heads
+
+
+LLAMA2_7B = LlamaShape(4096, 11008, 32, 32, 32, 32000, name="llama-2-7b")
+LLAMA2_13B = LlamaShape(5120, 13824, 40, 40, 40, 32000, name="llama-2-13b")
+
+
+def tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=512, max_seq=64, n_out=128):
+    return LlamaShape(hidden, inter, n_layers, n_heads, n_heads, vocab, max_seq, n_out=n_out, name="tiny")
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthetic packed layers: W ~ N(0, 0.02^2), per-group asymmetric min-max INT4, last n_out
+# columns kept fp16
+# ----------------------------------------------------------------------------------------------------
+def synthetic_quantlinear(name, in_f, out_f, n_out, group_size, seed, device, outlieridx=None):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    w = (torch.randn(out_f, in_f, generator=gen, dtype=torch.float32) * 0.02).to(device).half()
+    scale, zero = minmax_params(w, group_size)
+    wq = fake_quantize(w, scale, zero, group_size).half()
+    if n_out > 0:
+        wq[:, in_f - n_out:] = w[:, in_f - n_out:]
+    lin = nn.Linear(in_f, out_f, bias=False, dtype=torch.float16, device=device)
+    lin.weight.data = wq
+    ql = QuantLinear(4, in_f, out_f, False, torch.float16, n_out, group_size, True, name).to(device)
+    if outlieridx is None:
+        outlieridx = torch.arange(in_f - n_out, in_f, dtype=torch.int32, device=device)
+    ql.pack(lin, scale, zero, outlieridx.to(device))
+    ql.set_kernel()
+    return ql
+
+
+class _Attn(nn.Module):
+    pass
+
+
+class _Mlp(nn.Module):
+    pass
+
+
+class _Layer(nn.Module):
+    pass
+
+
+class _Inner(nn.Module):
+    pass
+
+
+class QuantLlama(nn.Module):
+    """Module tree with HF's attribute names; every decoder linear is a packed QuantLinear."""
+
+    def __init__(self, shape: LlamaShape, device="cuda:0", seed=0):
+        super().__init__()
+        assert shape.head_dim == 128, "the decode attention kernel is built for head_dim 128"
+        self.shape = shape
+        s = shape
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.model = _Inner()
+        self.model.embed_tokens = nn.Embedding(s.vocab, s.hidden, dtype=torch.float16, device=device)
+        self.model.embed_tokens.weight.data = (torch.randn(s.vocab, s.hidden, generator=gen) * 0.5).half().to(device)
+        self.model.norm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device),
+                                       requires_grad=False)
+        self.lm_head = nn.Linear(s.hidden, s.vocab, bias=False, dtype=torch.float16, device=device)
+        self.lm_head.weight.data = (torch.randn(s.vocab, s.hidden, generator=gen) * 0.02).half().to(device)
+        layers = []
+        kv = s.n_kv_heads * s.head_dim
+        for li in range(s.n_layers):
+            L = _Layer()
+            L.self_attn = _Attn()
+            L.mlp = _Mlp()
+            pre = f"model.layers.{li}."
+            sd = 1000 * li + seed * 7919
+            L.self_attn.q_proj = synthetic_quantlinear(pre + "self_attn.q_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 0, device)
+            L.self_attn.k_proj = synthetic_quantlinear(pre + "self_attn.k_proj", s.hidden, kv, s.n_out, s.group_size, sd + 1, device)
+            L.self_attn.v_proj = synthetic_quantlinear(pre + "self_attn.v_proj", s.hidden, kv, s.n_out, s.group_size, sd + 2, device)
+            # o_proj has its OWN outlier columns (per layer, reorder.py:38-46) -> runtime gather of its input
+            g2 = torch.Generator(device="cpu").manual_seed(sd + 99)
+            oidx = torch.randperm(s.hidden, generator=g2)[:max(s.n_out, 1)].sort().values.to(torch.int32) if s.n_out else None
+            L.self_attn.o_proj = synthetic_quantlinear(pre + "self_attn.o_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 3, device, oidx)
+            L.mlp.gate_proj = synthetic_quantlinear(pre + "mlp.gate_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 4, device)
+            L.mlp.up_proj = synthetic_quantlinear(pre + "mlp.up_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 5, device)
+            L.mlp.down_proj = synthetic_quantlinear(pre + "mlp.down_proj", s.inter, s.hidden, s.n_out, s.group_size, sd + 6, device)
+            L.input_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
+            L.post_attention_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
+            layers.append(L)
+        self.model.layers = nn.ModuleList(layers)
+        for prm in self.parameters():
+            prm.requires_grad_(False)
+        half = s.head_dim // 2
+        inv = 1.0 / (s.rope_theta ** (torch.arange(0, half, dtype=torch.float64) / half))
+        ang = torch.arange(s.max_seq, dtype=torch.float64)[:, None] * inv[None, :]
+        self.register_buffer("rope_cos", ang.cos().float().to(device), persistent=False)
+        self.register_buffer("rope_sin", ang.sin().float().to(device), persistent=False)
+
+    # ------------------------------------------------------------------ dense fp32 reference
+    @torch.no_grad()
+    def dense_weights(self):
+        """Dense dequantised fp32 weights per layer (through the HIP dequant kernel, itself bit-exact vs the oracle)."""
+        from . import qeft_cuda
+        out = []
+        for L in self.model.layers:
+            d = {}
+            for grp, names in (("self_attn", ("q_proj", "k_proj", "v_proj", "o_proj")), ("mlp", ("gate_proj", "up_proj", "down_proj"))):
+                for n in names:
+                    ql = getattr(getattr(L, grp), n)
+                    d[n] = qeft_cuda.dequantize_weight_4bit_qeft(ql.qweight, ql.scales, ql.scaled_zeros,
+                                                                 ql.oweight if ql.outlierfeatures else None).float()
+            out.append(d)
+        return out
+
+    @torch.no_grad()
+    def forward_dense_reference(self, tokens, dense=None):
+        """Plain PyTorch fp32 causal forward over the dense dequantised weights.  tokens [T] -> logits [T, vocab]."""
+        s = self.shape
+        dense = dense or self.dense_weights()
+        T = tokens.numel()
+        h = self.model.embed_tokens.weight[tokens].float()
+        cos, sin = self.rope_cos[:T], self.rope_sin[:T]
+
+        def rms(x, g):
+            return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + s.rms_eps) * g.float()
+
+        def rope(x):  # [T, H, 128]
+            a, b = x[..., :64], x[..., 64:]
+            c, sn = cos[:, None, :], sin[:, None, :]
+            return torch.cat([a * c - b * sn, b * c + a * sn], dim=-1)
+
+        mask = torch.full((T, T), float("-inf"), device=h.device).triu(1)
+        for L, d in zip(self.model.layers, dense):
+            x = rms(h, L.input_layernorm)
+            q = rope((x @ d["q_proj"].T).view(T, s.n_heads, 128))
+            k = rope((x @ d["k_proj"].T).view(T, s.n_kv_heads, 128))
+            v = (x @ d["v_proj"].T).view(T, s.n_kv_heads, 128)
+            rep = s.n_heads // s.n_kv_heads
+            k, v = k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1)
+            att = torch.einsum("thd,shd->hts", q, k) / math.sqrt(128) + mask
+            a = torch.einsum("hts,shd->thd", att.softmax(-1), v).reshape(T, s.hidden)
+            a = a[:, L.self_attn.o_proj.reorder_ids] if hasattr(L.self_attn.o_proj, "reorder_ids") else a
+            h = h + a @ d["o_proj"].T
+            x = rms(h, L.post_attention_layernorm)
+            act = torch.nn.functional.silu(x @ d["gate_proj"].T) * (x @ d["up_proj"].T)
+            h = h + act @ d["down_proj"].T
+        return rms(h, self.model.norm) @ self.lm_head.weight.float().T
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+class DecodeEngine:
+    """One decode token = a fixed list of C-ABI launches on static buffers (hipGraph-capturable)."""
+
+    def __init__(self, model: QuantLlama, use_graph=True):
+        self.m = model
+        s = model.shape
+        dev = model.lm_head.weight.device
+        self.dev = dev
+        self.lib = _lib.lib()
+        f16 = dict(dtype=torch.float16, device=dev)
+        self.tok = torch.zeros(1, dtype=torch.long, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.h = torch.zeros(s.hidden, **f16)
+        self.xn = torch.zeros(s.hidden, **f16)
+        kvd = s.n_kv_heads * s.head_dim
+        self.q = torch.zeros(s.hidden, **f16)
+        self.k = torch.zeros(kvd, **f16)
+        self.v = torch.zeros(kvd, **f16)
+        self.att = torch.zeros(s.hidden, **f16)
+        self.gate = torch.zeros(s.inter, **f16)
+        self.up = torch.zeros(s.inter, **f16)
+        self.act = torch.zeros(s.inter, **f16)
+        self.hn = torch.zeros(1, s.hidden, **f16)
+        self.logits = torch.zeros(1, s.vocab, **f16)
+        self.kc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
+        self.vc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
+        self.greedy = False
+        self.graph = None
+        self.use_graph = use_graph
+        # per-layer argument packs (host arrays of device pointers must stay alive)
+        self.packs = []
+        for L in model.model.layers:
+            a, mlp = L.self_attn, L.mlp
+            qkv = [a.q_proj, a.k_proj, a.v_proj]
+            gu = [mlp.gate_proj, mlp.up_proj]
+            no = s.n_out
+            self.packs.append(dict(
+                qkv=(_ptr_array([l.qweight for l in qkv]), _ptr_array([l.scales for l in qkv]),
+                     _ptr_array([l.scaled_zeros for l in qkv]),
+                     _ptr_array([l.oweight_interleaved for l in qkv]) if no else None,
+                     _ptr_array([self.q, self.k, self.v]), (ctypes.c_int * 3)(s.hidden, kvd, kvd)),
+                gu=(_ptr_array([l.qweight for l in gu]), _ptr_array([l.scales for l in gu]),
+                    _ptr_array([l.scaled_zeros for l in gu]),
+                    _ptr_array([l.oweight_interleaved for l in gu]) if no else None,
+                    _ptr_array([self.gate, self.up]), (ctypes.c_int * 2)(s.inter, s.inter)),
+            ))
+
+    def reset(self):
+        self.pos.zero_()
+
+    # -- the launch sequence ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def _launch_token(self):
+        s, lib, ck = self.m.shape, self.lib, _lib.check
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        torch.index_select(self.m.model.embed_tokens.weight, 0, self.tok, out=self.h.view(1, -1))
+        g, no = s.group_size, s.n_out
+        for li, L in enumerate(self.m.model.layers):
+            a, mlp, pk = L.self_attn, L.mlp, self.packs[li]
+            ck(lib.qeft_rmsnorm(self.h.data_ptr(), None, L.input_layernorm.data_ptr(), None, self.xn.data_ptr(), 1,
+                                s.hidden, s.rms_eps, st))
+            qw, sc, sz, ow, ys, ns = pk["qkv"]
+            ck(lib.qeft_gemv_w4_group(self.xn.data_ptr(), 3, qw, sc, sz, ow, None, ys, ns, s.hidden, g, no, st))
+            ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
+                                         self.m.rope_cos.data_ptr(), self.m.rope_sin.data_ptr(),
+                                         self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                         self.att.data_ptr(), s.n_heads, s.n_kv_heads, s.max_seq, st))
+            o = a.o_proj
+            ids = o.reorder_ids32.data_ptr() if hasattr(o, "reorder_ids32") else None
+            ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
+                                      o.scaled_zeros.data_ptr(), o.oweight_interleaved.data_ptr() if no else None,
+                                      None, ids, self.h.data_ptr(), self.h.data_ptr(), 1, s.hidden, s.hidden, g, no, st))
+            ck(lib.qeft_rmsnorm(self.h.data_ptr(), None, L.post_attention_layernorm.data_ptr(), None,
+                                self.xn.data_ptr(), 1, s.hidden, s.rms_eps, st))
+            qw, sc, sz, ow, ys, ns = pk["gu"]
+            ck(lib.qeft_gemv_w4_group(self.xn.data_ptr(), 2, qw, sc, sz, ow, None, ys, ns, s.hidden, g, no, st))
+            ck(lib.qeft_silu_mul(self.gate.data_ptr(), self.up.data_ptr(), self.act.data_ptr(), s.inter, st))
+            d = mlp.down_proj
+            ck(lib.qeft_gemv_w4_fused(self.act.data_ptr(), d.qweight.data_ptr(), d.scales.data_ptr(),
+                                      d.scaled_zeros.data_ptr(), d.oweight_interleaved.data_ptr() if no else None,
+                                      None, None, self.h.data_ptr(), self.h.data_ptr(), 1, s.hidden, s.inter, g, no, st))
+        ck(lib.qeft_rmsnorm(self.h.data_ptr(), None, self.m.model.norm.data_ptr(), None, self.hn.data_ptr(), 1,
+                            s.hidden, s.rms_eps, st))
+        torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
+        if self.greedy:
+            torch.argmax(self.logits, dim=-1, out=self.tok)
+        self.pos.add_(1)
+
+    def capture(self):
+        """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires)."""
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        pos0, tok0 = self.pos.clone(), self.tok.clone()
+        with torch.cuda.stream(side):
+            self._launch_token()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.pos.copy_(pos0)
+        self.tok.copy_(tok0)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._launch_token()
+        self.pos.copy_(pos0)
+        self.tok.copy_(tok0)
+
+    def step(self):
+        """Run one token: consumes self.tok at position self.pos, leaves logits (and, if greedy, the next token)."""
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self._launch_token()
+
+    @torch.no_grad()
+    def teacher_forced_logits(self, tokens):
+        """Feed `tokens` one by one from position 0; returns fp32 logits [T, vocab] (main.py:340-371 protocol)."""
+        self.reset()
+        self.greedy = False
+        outs = []
+        for t in tokens.tolist():
+            self.tok.fill_(t)
+            self.step()
+            outs.append(self.logits[0].float().clone())
+        return torch.stack(outs)
+
+
+def nll_from_logits(logits, tokens):
+    """Mean next-token NLL of a teacher-forced run (main.py:291-305 / :369-371)."""
+    return torch.nn.functional.cross_entropy(logits[:-1].float(), tokens[1:].to(logits.device)).item()

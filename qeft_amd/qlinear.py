@@ -161,7 +161,7 @@ class QuantLinear(nn.Module):
         if sym:
             zeros = zeros + 2 ** (self.bits - 1)
         if linear.bias is not None:
-            self.bias = linear.bias.to(dtype)
+            self.bias = linear.bias.detach().to(dtype)
 
         scale_zeros = zeros * scales
         rep = 1 if self.group_size == self.infeatures and scales.shape[1] == self.infeatures else self.group_size

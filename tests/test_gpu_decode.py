@@ -1,0 +1,151 @@
+"""GPU parity of the decode-step helpers and of the whole decode engine.
+Floating-point kernels: compared with a plain PyTorch fp32 reference of the same op (tolerances in each test)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qeft_oracle as O
+from util import REL_TOL, layer_to_torch, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("m,h", [(1, 4096), (3, 5120), (2, 256)])
+def test_rmsnorm_vs_torch_fp32(m, h):
+    from qeft_amd import _lib
+    torch.manual_seed(0)
+    x = torch.randn(m, h, device=DEV).half()
+    add = torch.randn(m, h, device=DEV).half()
+    g = (1 + 0.1 * torch.randn(h, device=DEV)).half()
+    y = torch.empty_like(x)
+    res = torch.empty_like(x)
+    _lib.check(_lib.lib().qeft_rmsnorm(x.data_ptr(), None, g.data_ptr(), None, y.data_ptr(), m, h, 1e-5, _st()))
+    ref = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5) * g.float()
+    assert torch.allclose(y.float(), ref, rtol=2e-3, atol=2e-3)
+    _lib.check(_lib.lib().qeft_rmsnorm(x.data_ptr(), add.data_ptr(), g.data_ptr(), res.data_ptr(), y.data_ptr(), m, h,
+                                       1e-5, _st()))
+    hsum = (x.float() + add.float()).half().float()
+    ref = hsum * torch.rsqrt(hsum.pow(2).mean(-1, keepdim=True) + 1e-5) * g.float()
+    assert torch.equal(res.float(), hsum)
+    assert torch.allclose(y.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_silu_mul_vs_torch_fp32():
+    from qeft_amd import _lib
+    torch.manual_seed(1)
+    g = torch.randn(11008, device=DEV).half() * 3
+    u = torch.randn(11008, device=DEV).half()
+    o = torch.empty_like(g)
+    _lib.check(_lib.lib().qeft_silu_mul(g.data_ptr(), u.data_ptr(), o.data_ptr(), g.numel(), _st()))
+    ref = torch.nn.functional.silu(g.float()) * u.float()
+    assert torch.allclose(o.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("n_heads,n_kv,steps", [(4, 4, 70), (8, 2, 300)])
+def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps):
+    from qeft_amd import _lib
+    torch.manual_seed(2)
+    hd, max_seq = 128, 512
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, dtype=torch.float64) / 64))
+    ang = torch.arange(max_seq, dtype=torch.float64)[:, None] * inv[None]
+    cs, sn = ang.cos().float().to(DEV), ang.sin().float().to(DEV)
+    kc = torch.zeros(n_kv, max_seq, hd, device=DEV, dtype=torch.float16)
+    vc = torch.zeros_like(kc)
+    pos = torch.zeros(1, dtype=torch.int32, device=DEV)
+    Q = torch.randn(steps, n_heads, hd, device=DEV).half()
+    K = torch.randn(steps, n_kv, hd, device=DEV).half()
+    V = torch.randn(steps, n_kv, hd, device=DEV).half()
+    out = torch.empty(n_heads * hd, device=DEV, dtype=torch.float16)
+
+    def rope(x, t):
+        a, b = x[..., :64].float(), x[..., 64:].float()
+        return torch.cat([a * cs[t] - b * sn[t], b * cs[t] + a * sn[t]], -1)
+
+    kr = torch.stack([rope(K[t], t) for t in range(steps)]).half().float()   # cache holds fp16
+    for t in range(steps):
+        pos.fill_(t)
+        _lib.check(_lib.lib().qeft_rope_attn_decode(Q[t].data_ptr(), K[t].data_ptr(), V[t].data_ptr(), cs.data_ptr(),
+                                                    sn.data_ptr(), kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
+                                                    out.data_ptr(), n_heads, n_kv, max_seq, _st()))
+        if t in (0, 1, steps // 2, steps - 1):
+            q = rope(Q[t], t)                                                  # [H, 128]
+            rep = n_heads // n_kv
+            kk = kr[:t + 1].repeat_interleave(rep, 1)                          # [L, H, 128]
+            vv = V[:t + 1].float().repeat_interleave(rep, 1)
+            att = torch.einsum("hd,lhd->hl", q, kk) / math.sqrt(hd)
+            ref = torch.einsum("hl,lhd->hd", att.softmax(-1), vv).reshape(-1)
+            torch.cuda.synchronize()
+            assert torch.allclose(out.float(), ref, rtol=5e-3, atol=5e-3), t
+    assert torch.allclose(kc[:, :steps].float().transpose(0, 1), kr, atol=1e-3)
+
+
+@pytest.mark.parametrize("ns,k,r", [((4096, 4096, 4096), 4096, 128), ((11008, 11008), 4096, 128), ((256, 64, 64), 512, 0),
+                                    ((512, 256), 11008, 128)])
+def test_grouped_gemv_equals_separate_launches(ns, k, r):
+    """q/k/v (gate/up) in one launch == the per-linear GEMV, bit for bit (same per-row arithmetic)."""
+    from qeft_amd import _lib, qeft_cuda
+    g = 128
+    layers = [layer_to_torch(O.make_layer(n, k, r, g, seed=10 + i), DEV) for i, n in enumerate(ns)]
+    x = torch.from_numpy(O.make_activation(1, k, r, seed=3)).to(DEV)
+    ys = [torch.empty(1, n, device=DEV, dtype=torch.float16) for n in ns]
+
+    def arr(ts):
+        a = (ctypes.c_void_p * len(ts))()
+        for i, t in enumerate(ts):
+            a[i] = t.data_ptr()
+        return a
+    _lib.check(_lib.lib().qeft_gemv_w4_group(
+        x.data_ptr(), len(ns), arr([l["qweight"] for l in layers]), arr([l["scales"] for l in layers]),
+        arr([l["scaled_zeros"] for l in layers]), arr([l["oweight_interleaved"] for l in layers]) if r else None, None,
+        arr(ys), (ctypes.c_int * len(ns))(*ns), k, g, r, _st()))
+    for l, n, y in zip(layers, ns, ys):
+        if r:
+            ref = qeft_cuda.gemv_4bit_qeft(x, l["qweight"], l["scales"], l["scaled_zeros"], l["oweight_interleaved"],
+                                           1, n, k, g)
+        else:
+            ref = qeft_cuda.gemv_4bit(x, l["qweight"], l["scales"], l["scaled_zeros"], 1, n, k, g)
+        torch.cuda.synchronize()
+        assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_decode_engine_matches_dense_fp32_model(use_graph):
+    """Teacher-forced logits / NLL of the HIP decode engine vs a plain PyTorch fp32 model over the dense
+    dequantised weights, on a tiny Llama-shaped model (SURVEY.md §8d 'PPL parity on synthetic weights')."""
+    from qeft_amd.llama import DecodeEngine, QuantLlama, nll_from_logits, tiny_shape
+    shape = tiny_shape(n_layers=3, hidden=256, inter=512, n_heads=2, vocab=384, max_seq=64)
+    model = QuantLlama(shape, DEV, seed=1)
+    eng = DecodeEngine(model, use_graph=use_graph)
+    tokens = torch.randint(0, shape.vocab, (40,), generator=torch.Generator().manual_seed(0)).to(DEV)
+    got = eng.teacher_forced_logits(tokens)
+    ref = model.forward_dense_reference(tokens)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() / scale < 2e-2
+    assert abs(nll_from_logits(got, tokens) - nll_from_logits(ref, tokens)) < 5e-3
+
+
+def test_decode_engine_greedy_graph_equals_eager():
+    from qeft_amd.llama import DecodeEngine, QuantLlama, tiny_shape
+    shape = tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=384, max_seq=64)
+    model = QuantLlama(shape, DEV, seed=2)
+    seqs = []
+    for use_graph in (False, True):
+        eng = DecodeEngine(model, use_graph=use_graph)
+        eng.greedy = True
+        eng.reset()
+        eng.tok.fill_(5)
+        toks = []
+        for _ in range(24):
+            eng.step()
+            toks.append(int(eng.tok.item()))
+        seqs.append(toks)
+    assert seqs[0] == seqs[1]

@@ -1,0 +1,147 @@
+"""GPU tests of the host-side mirror: QuantLinear forward dispatch, o_proj gather, training autograd, checkpoint I/O."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import qeft_oracle as O
+from util import REL_TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(n, k, r, g, name, bias=False, seed=0, fused=True):
+    from qeft_amd.qlinear import QuantLinear
+    bufs = O.make_layer(n, k, r, g, seed=seed, bias=bias)
+    scale, zero = O.minmax_params(np.zeros((1, 1), np.float32), 1)  # unused, keep flake quiet
+    w = torch.from_numpy(bufs["fake_weight"])
+    lin = torch.nn.Linear(k, n, bias=bias, dtype=torch.float16)
+    lin.weight.data = w
+    if bias:
+        lin.bias.data = torch.from_numpy(bufs["bias"])
+    rng = np.random.default_rng(seed)
+    oidx = torch.from_numpy(np.sort(rng.choice(k, size=max(r, 1), replace=False)).astype(np.int32))
+    s, z = O.minmax_params(rng.standard_normal((n, k), dtype=np.float32) * 0 + bufs["fake_weight"].astype(np.float32), g)
+    # parameters must be the ones the fake weight was quantised with: recompute from the original draw
+    rng2 = np.random.default_rng(seed)
+    w0 = (rng2.standard_normal((n, k), dtype=np.float32) * 0.02).astype(np.float16)
+    s, z = O.minmax_params(w0, g)
+    ql = QuantLinear(4, k, n, bias, torch.float16, r, g, True, name)
+    ql.pack(lin, torch.from_numpy(s), torch.from_numpy(z), oidx)
+    ql = ql.to(DEV)
+    ql.fused = fused
+    ql.set_kernel()
+    return ql, bufs, oidx.numpy()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("m", [1, 5, 8, 40])
+@pytest.mark.parametrize("name", ["model.layers.0.mlp.up_proj", "model.layers.0.self_attn.o_proj"])
+def test_forward_dispatch_matches_oracle(name, m, fused):
+    n, k, r, g = 256, 1024, 128, 128
+    ql, bufs, oidx = build(n, k, r, g, name, bias=True, seed=3, fused=fused)
+    for key in ("qweight", "scales", "scaled_zeros", "oweight", "oweight_interleaved"):
+        assert np.array_equal(ql.state_dict()[key].cpu().numpy().view(np.uint8), bufs[key].view(np.uint8)), key
+    x = O.make_activation(m, k, r, seed=m)
+    ids = O.sparse_to_dense_ids(oidx, k) if "o_proj" in name else None
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], bufs["bias"], g,
+                          reorder_ids=ids).astype(np.float64)
+    y = ql(torch.from_numpy(x).to(DEV).view(1, m, k))
+    torch.cuda.synchronize()
+    assert y.shape == (1, m, n)
+    tol = REL_TOL if fused else 2e-3   # unfused GEMM route keeps the reference's dead-nibble residual
+    assert rel_err(y.detach().cpu().numpy().reshape(m, n), yref) < tol
+
+
+def test_forward_normal_without_outliers():
+    n, k, g = 136, 512, 128
+    ql, bufs, _ = build(n, k, 0, g, "model.layers.0.mlp.up_proj", seed=4)
+    for m in (2, 17):
+        x = O.make_activation(m, k, 0, seed=m)
+        yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], None, None, g)
+        y = ql(torch.from_numpy(x).to(DEV))
+        torch.cuda.synchronize()
+        assert rel_err(y.cpu().numpy(), yref.astype(np.float64)) < REL_TOL
+
+
+def test_training_autograd_matches_dense_linear_autograd():
+    """set_kernel(training=True) + set_for_wct(): forward/backward vs torch autograd through a dense fp32 linear
+    holding the dequantised weight (the mathematically correct backward)."""
+    n, k, r, g, m = 256, 1024, 128, 128, 48
+    ql, bufs, _ = build(n, k, r, g, "model.layers.0.mlp.up_proj", seed=5)
+    ql.set_kernel(training=True)
+    ql.set_for_wct()
+    x = torch.from_numpy(O.make_activation(m, k, r, seed=9)).to(DEV).requires_grad_(True)
+    y = ql(x)
+    gy = (torch.randn(m, n, generator=torch.Generator().manual_seed(1)) * 0.1).half().to(DEV)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    w = torch.from_numpy(O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], g)).to(DEV)
+    xr = x.detach().float().requires_grad_(True)
+    wq = w[:, :k - r].clone()
+    ow = w[:, k - r:].clone().requires_grad_(True)
+    yr = xr @ torch.cat([wq, ow], 1).T
+    yr.backward(gy.float())
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < REL_TOL
+    assert rel_err(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < REL_TOL
+    assert ql.oweight.grad.dtype == torch.float32
+    assert rel_err(ql.oweight.grad.cpu().numpy(), ow.grad.cpu().numpy()) < REL_TOL
+    assert ql.qweight.grad is None
+
+
+def test_checkpoint_roundtrip_and_finetuned_delta(tmp_path):
+    from argparse import Namespace
+    from qeft_amd import checkpoint
+    from qeft_amd.qlinear import QuantLinear
+    from qeft_amd.quant import find_layers, lm_pack, minmax_params, fake_quantize
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up_proj = torch.nn.Linear(256, 64, bias=False, dtype=torch.float16)
+            self.o_proj = torch.nn.Linear(64, 256, bias=True, dtype=torch.float16)
+
+    torch.manual_seed(0)
+    net = Tiny()
+    infos = {}
+    for name, lin in find_layers(net).items():
+        k = lin.in_features
+        r, g = (32, 64) if name == "o_proj" else (128, 128)
+        w = (torch.randn_like(lin.weight.float()) * 0.02).half()
+        s, z = minmax_params(w, g)
+        wq = fake_quantize(w, s, z, g).half()
+        wq[:, k - r:] = w[:, k - r:]
+        lin.weight.data = wq
+        infos[name] = Namespace(bits=4, sym=False, group_size=g, n_out=r, reorder=True, scale_group=s, zero_group=z,
+                                out_ids=torch.arange(k - r, k, dtype=torch.int32))
+    x = torch.randn(3, 256).half()
+    lm_pack(net, infos)
+    path = str(tmp_path / "ckpt" / "model.pth")
+    checkpoint.save_packed(net, infos, path)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"model_state_dict", "quantinfos", "packing", "dtype", "bits", "group_size"}
+    assert ck["packing"] is True and ck["bits"] == 4
+    assert vars(ck["quantinfos"]["up_proj"]) == dict(bits=4, sym=False, group_size=128, n_out=128, reorder=True)
+    m2 = checkpoint.load_packed(Tiny(), path, device=DEV)
+    q1, q2 = find_layers(net, [QuantLinear]), find_layers(m2, [QuantLinear])
+    for name in q1:
+        for key, val in q1[name].state_dict().items():
+            got = q2[name].state_dict()[key].cpu()
+            if key == "oweight":   # set_kernel() left-pads oweight to a multiple of 64 columns (qlinear.py:221-222)
+                assert got.shape[1] % 64 == 0 and torch.all(got[:, :got.shape[1] - val.shape[1]] == 0)
+                got = got[:, -val.shape[1]:]
+            assert torch.equal(val, got), (name, key)
+    y0 = m2.up_proj(x.to(DEV))
+    # fine-tuned delta: only oweight travels, and the interleaved copy is refreshed on load
+    new_ow = (q2["up_proj"].oweight.float() * 1.5).half()
+    with torch.no_grad():
+        q2["up_proj"].oweight.copy_(new_ow)
+    d = checkpoint.save_finetuned(m2, path, str(tmp_path / "ft"))
+    assert set(torch.load(d, weights_only=False)) == {"oweight_state_dict", "base_path"}
+    m3 = checkpoint.load_packed(Tiny(), d, device=DEV)
+    y1 = m3.up_proj(x.to(DEV))
+    w0 = torch.from_numpy(O.dequant_dense(*(q1["up_proj"].state_dict()[kk].numpy() for kk in
+                                            ("qweight", "scales", "scaled_zeros")), new_ow.cpu().numpy(), 128))
+    torch.cuda.synchronize()
+    assert rel_err(y1.cpu().numpy(), (x.float() @ w0.T).numpy()) < REL_TOL
+    assert not torch.allclose(y0, y1)
