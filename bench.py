@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Decode benchmark of the MI355X packed-weight quantized linear path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): Llama-2-7B shapes, w4 g128 r128, batch 1.  A "step" is ONE decode token of
+the whole model: 32 layers x (RMSNorm, q|k|v grouped GEMV, rotary+KV-append+attention, o_proj GEMV with the o_proj
+gather and the residual, RMSNorm, gate|up grouped GEMV, SiLU*mul, down_proj GEMV with the residual), final norm,
+fp16 lm_head, greedy argmax — captured once into a hipGraph and replayed.  Weights are synthetic (seeded), inputs
+are resident in HBM; the timed region is K graph replays bracketed by barrier + synchronize.
+
+N > 1: every quantized linear is row-sharded over the N ranks and one RCCL all-gather per linear rebuilds the
+activations (strong scaling: the model is fixed).
+
+The same JSON line carries
+  roofline      for the dominant kernel (the W4 GEMV): algorithmic bytes of all GEMV launches of one token /
+                their HIP-event-timed duration (the token's GEMV launches replayed back to back from a graph on the
+                launch stream; the event time includes the ~1.3 us inter-kernel gaps, so it under-states the
+                per-kernel rate rocprofv3 reports), against 8 TB/s.
+  cpu_baseline  the reference's CPU path (dense nn.Linear on the dequantised weights, oracle/) timed on the host cores
+                for the 7 linears of one layer, scaled to a token.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(shape, reps=8):
+    """Reference CPU path on a bounded sample: one decoder layer's 7 linears, m = 1, fp32 nn.Linear on the
+    dequantised weights.  Returns tokens/s-equivalent = 1 / (n_layers * sum_t)."""
+    import numpy as np
+    from oracle import qeft_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    shapes = [(shape.hidden, shape.hidden)] * 4 + [(shape.inter, shape.hidden)] * 2 + [(shape.hidden, shape.inter)]
+    uniq = {}
+    total = 0.0
+    for (n, k) in shapes:
+        if (n, k) not in uniq:
+            bufs = O.make_layer(n, k, shape.n_out, shape.group_size, seed=n + k)
+            w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], shape.group_size)
+            lin = torch.nn.Linear(k, n, bias=False)
+            lin.weight.data = torch.from_numpy(w)
+            x = torch.from_numpy(O.make_activation(1, k, shape.n_out, seed=1).astype(np.float32))
+            with torch.no_grad():
+                for _ in range(2):
+                    lin(x)
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    lin(x)
+                    ts.append(time.perf_counter() - t0)
+            uniq[(n, k)] = sorted(ts)[len(ts) // 2]
+        total += uniq[(n, k)]
+    return {"value": round(1.0 / (shape.n_layers * total), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"7 linears of one {shape.name} layer, m=1, fp32 torch.nn.Linear on oracle-dequantised weights, "
+                      f"median of {reps}; linears only, x{shape.n_layers} layers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        group = dist.group.WORLD
+
+    from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, DecodeEngine, QuantLlama, tiny_shape
+    import dataclasses
+    base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B, "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
+    shape = dataclasses.replace(base, max_seq=max(512, args.warmup + args.steps + 8))
+
+    t_build = time.time()
+    model = QuantLlama(shape, dev, seed=0, fast_init=True)
+    eng = DecodeEngine(model, use_graph=not args.no_graph, tp_group=group)
+    eng.greedy = True
+    torch.cuda.synchronize(dev)
+    t_build = time.time() - t_build
+
+    graph_ok = not args.no_graph
+    if graph_ok:
+        try:
+            eng.capture()
+        except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            eng.use_graph, eng.graph, graph_ok = False, None, False
+            torch.cuda.synchronize(dev)
+
+    # ---- warm-up: W tokens (they also build the KV-cache context, cf. benchmark.py ctx 64)
+    eng.reset()
+    eng.tok.fill_(1)
+    for _ in range(args.warmup):
+        eng.step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last_tok = int(eng.tok.item())
+
+    # ---- roofline of the dominant kernel: the token's GEMV launches alone, back to back, HIP-event timed
+    roof = None
+    try:
+        g2 = eng.capture(linears_only=True) if graph_ok else None
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            g2.replay() if g2 is not None else eng._launch_token(True)
+        torch.cuda.synchronize(dev)
+        e0.record(torch.cuda.current_stream(dev))
+        for _ in range(reps):
+            g2.replay() if g2 is not None else eng._launch_token(True)
+        e1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        launches = 4 * shape.n_layers
+        us_per_launch = e0.elapsed_time(e1) * 1e3 / (reps * launches)
+        bytes_per_launch = eng.weight_bytes_per_token() / launches
+        achieved = bytes_per_launch / us_per_launch / 1e3  # GB/s
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "qeft::gemv_w4_group_kernel / gemv_w4_kernel (4 launches per layer)",
+                "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3)}
+    except Exception as e:  # never lose the headline number because of the side measurement
+        if rank == 0:
+            print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
+
+    if rank == 0:
+        ms = dt * 1e3 / args.steps
+        out = {
+            "metric": "decode tokens/sec, Llama-2-7B w4 g128 r128" if args.model == "7b" else f"decode tokens/sec, {shape.name} w4 g128 r128",
+            "value": round(args.steps / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{shape.name} w4 g{shape.group_size} r{shape.n_out} full decode step, batch 1, "
+                                   f"greedy, KV context {args.warmup}..{args.warmup + args.steps} tokens",
+                       "layers": shape.n_layers, "hipgraph": graph_ok,
+                       "parallelism": f"tp{world} row-sharded QuantLinear + all-gather" if world > 1 else "single GPU",
+                       "build_s": round(t_build, 1), "last_token": last_tok},
+        }
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(shape)
+            except Exception as e:
+                print(f"[bench] cpu baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,10 +99,20 @@ int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, q
 
 /* Up to 3 quantized linears that read the SAME x (q/k/v or gate/up) in one launch, batch 1.
  * Host arrays of `nparts` device pointers; oweight_il / bias entries may be NULL (all-or-none for oweight_il).
- * Equivalent to nparts calls of gemv_4bit_qeft (gemv_cuda_qeft.cu:392-513) on identical in_feats. */
-int qeft_gemv_w4_group(const void* x, int nparts, const void* const* qweight, const void* const* scales,
-                       const void* const* scaled_zeros, const void* const* oweight_il, const void* const* bias,
-                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream);
+ * Equivalent to nparts calls of gemv_4bit_qeft (gemv_cuda_qeft.cu:392-513) on identical in_feats.
+ * norm_gamma != NULL: the input is RMS-normalised while it is staged (x * rsqrt(mean x^2 + norm_eps) * gamma, the
+ * arithmetic of qeft_rmsnorm / layernorm.cu:26-76), i.e. the decoder's input_layernorm / post_attention_layernorm
+ * fused into the projection that consumes it (K <= 16384). */
+int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
+                       const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
+                       const void* const* oweight_il, const void* const* bias, void* const* y, const int* n, int k,
+                       int group_size, int n_out, qeft_stream_t stream);
+
+/* down_proj of the decode step in one launch: y = W . (silu(gate) * up) (+ bias) (+ residual), batch 1.
+ * The activation is formed while x is staged, rounded to fp16 exactly like qeft_silu_mul (K <= 16384). */
+int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, const void* scales,
+                      const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
+                      void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream);
 
 /* y = rmsnorm(x (+ add)) * gamma, fp32 statistics (role of layernorm_forward_cuda, qeft/kernel/layernorm/layernorm.cu:26-76).
  * If add != NULL the sum x + add is normalised and, if res_out != NULL, also written there (fused residual). */

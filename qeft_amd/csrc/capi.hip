@@ -8,6 +8,7 @@
 namespace qeft {
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
 hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
+hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st);
 hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int H,
                           float eps, hipStream_t st);
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
@@ -83,6 +84,8 @@ int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, c
     a.K = k;
     a.G = group_size;
     a.n_out = n_out;
+    a.xt_aux = nullptr;
+    a.xt_eps = 0.f;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
     return finish(qeft::gemv_w4_dispatch(a, m, (hipStream_t)stream));
@@ -150,9 +153,10 @@ int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, q
     return finish(qeft::pack_oweight_launch(oweight, oweight_il, n, n_out, (hipStream_t)stream));
 }
 
-int qeft_gemv_w4_group(const void* x, int nparts, const void* const* qweight, const void* const* scales,
-                       const void* const* scaled_zeros, const void* const* oweight_il, const void* const* bias,
-                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream) {
+int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
+                       const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
+                       const void* const* oweight_il, const void* const* bias, void* const* y, const int* n, int k,
+                       int group_size, int n_out, qeft_stream_t stream) {
     if (nparts < 1 || nparts > 3) return QEFT_ERR_SHAPE;
     if (!x || !qweight || !scales || !scaled_zeros || !y || !n) return QEFT_ERR_NULL;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;
@@ -176,7 +180,38 @@ int qeft_gemv_w4_group(const void* x, int nparts, const void* const* qweight, co
     g.G = group_size;
     g.n_out = n_out;
     g.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
+    if (norm_gamma && !aligned16(norm_gamma)) return QEFT_ERR_ALIGN;
+    g.xt_aux = (const qeft::f16*)norm_gamma;
+    g.xt_eps = norm_eps;
     return finish(qeft::gemv_w4_group_dispatch(g, nparts, (hipStream_t)stream));
+}
+
+int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, const void* scales,
+                      const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
+                      void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    if (int e = check_common(n, k, group_size, n_out)) return e;
+    if (!gate || !up || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
+    if (!aligned16(gate) || !aligned16(up) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight_il)))
+        return QEFT_ERR_ALIGN;
+    if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;
+    qeft::GemvArgs a;
+    a.x = (const qeft::f16*)gate;
+    a.qw = (const uint8_t*)qweight;
+    a.scales = (const qeft::f16*)scales;
+    a.zeros = (const qeft::f16*)scaled_zeros;
+    a.ow_il = (const qeft::f16*)oweight_il;
+    a.bias = (const qeft::f16*)bias;
+    a.ids = nullptr;
+    a.residual = (const qeft::f16*)residual;
+    a.y = (qeft::f16*)y;
+    a.N = n;
+    a.K = k;
+    a.G = group_size;
+    a.n_out = n_out;
+    a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
+    a.xt_aux = (const qeft::f16*)up;
+    a.xt_eps = 0.f;
+    return finish(qeft::gemv_w4_silu_dispatch(a, (hipStream_t)stream));
 }
 
 int qeft_rmsnorm(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int hidden,

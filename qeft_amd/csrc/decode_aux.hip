@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     float* qs = sc + max_seq;                // [128] rotated, pre-scaled q
     f16* knew = (f16*)(qs + HD);             // [128]
     f16* vnew = knew + HD;                   // [128]
-    float* part = (float*)(vnew + HD);       // [2][128] output partials
+    float* part = (float*)(vnew + HD);       // [16][128] output partials
     __shared__ float sm[4];
 
     const int h = blockIdx.x, t = threadIdx.x;
@@ -132,23 +132,35 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     }
     __syncthreads();
 
+    // scores: 4 lanes per position (32 dims each, q quarter kept in registers), 64 positions per pass
+    const int qd = t & 3;
+    float qreg[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) qreg[j] = qs[qd * 32 + j];
     float lmax = -3.0e38f;
-    for (int p = t; p < L; p += 256) {
+    for (int p0 = 0; p0 < L; p0 += 64) {
+        const int p = p0 + (t >> 2);
         float s = 0.f;
-        if (p == pos) {
-#pragma unroll 8
-            for (int d = 0; d < HD; ++d) s += qs[d] * (float)knew[d];
-        } else {
-            const h8* row = (const h8*)(kch + (size_t)p * HD);
+        if (p < L) {
+            if (p == pos) {
 #pragma unroll
-            for (int j = 0; j < HD / 8; ++j) {
-                const h8 kv = row[j];
+                for (int j = 0; j < 32; ++j) s += qreg[j] * (float)knew[qd * 32 + j];
+            } else {
+                const h8* row = (const h8*)(kch + (size_t)p * HD + qd * 32);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += qs[j * 8 + e] * (float)kv[e];
+                for (int j = 0; j < 4; ++j) {
+                    const h8 kv = row[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += qreg[j * 8 + e] * (float)kv[e];
+                }
             }
         }
-        sc[p] = s;
-        lmax = fmaxf(lmax, s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (p < L) {
+            if (qd == 0) sc[p] = s;
+            lmax = fmaxf(lmax, s);
+        }
     }
     const float mx = block_max_256(lmax, sm);
     float lsum = 0.f;
@@ -160,15 +172,26 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     const float inv = 1.f / block_sum_256(lsum, sm);
     __syncthreads();
 
-    const int d = t & 127, half = t >> 7;
-    float o = 0.f;
-    for (int p = half; p < L; p += 2) {
-        const float vv = (p == pos) ? (float)vnew[d] : (float)vch[(size_t)p * HD + d];
-        o += sc[p] * vv;
+    // P.V: thread = (8-dim group, 1 of 16 position classes); 16-byte V loads; partials combined through LDS
+    const int dg = t & 15, pg = t >> 4;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int p = pg; p < L; p += 16) {
+        const h8 vv = (p == pos) ? *(const h8*)(vnew + dg * 8) : *(const h8*)(vch + (size_t)p * HD + dg * 8);
+        const float w = sc[p];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += w * (float)vv[e];
     }
-    part[half * HD + d] = o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[pg * HD + dg * 8 + e] = o[e];
     __syncthreads();
-    if (t < HD) out[h * HD + t] = (f16)((part[t] + part[HD + t]) * inv);
+    if (t < HD) {
+        float acc = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc += part[g * HD + t];
+        out[h * HD + t] = (f16)(acc * inv);
+    }
 }
 
 hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int H,
@@ -187,7 +210,7 @@ hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, h
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
                                    void* vc, const int* pos, void* out, int n_heads, int n_kv, int max_seq,
                                    hipStream_t st) {
-    const size_t smem = (size_t)max_seq * 4 + 128 * 4 + 2 * 128 * 2 + 2 * 128 * 4;
+    const size_t smem = (size_t)max_seq * 4 + 128 * 4 + 2 * 128 * 2 + 16 * 128 * 4;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)rope_attn_decode_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

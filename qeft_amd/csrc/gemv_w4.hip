@@ -93,14 +93,18 @@ hipError_t gemv_w4_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
     return hipSuccess;
 }
 
-// ---- grouped launch (decode engine): up to 3 linears sharing x, batch 1
+// ---- grouped launch (decode engine): up to 3 linears sharing x, batch 1, optional fused RMSNorm on x
 template <int RGI, int D>
 static hipError_t launch_group(const GemvGroupArgs& g, int nblocks, hipStream_t st) {
     const size_t smem = gemv_smem_bytes(kNW, RGI, 1, g.K, g.G, g.n_out);
-    if (g.n_out > 0)
-        hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, true>), dim3(nblocks), dim3(kNW * 64), smem, st, g);
-    else
-        hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, false>), dim3(nblocks), dim3(kNW * 64), smem, st, g);
+    const dim3 grid(nblocks), block(kNW * 64);
+    if (g.xt_aux) {
+        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, true, 1>), grid, block, smem, st, g);
+        else hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, false, 1>), grid, block, smem, st, g);
+    } else {
+        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, true, 0>), grid, block, smem, st, g);
+        else hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, false, 0>), grid, block, smem, st, g);
+    }
     return hipGetLastError();
 }
 
@@ -120,11 +124,36 @@ hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st) {
         g.blk_end[p] = acc;
     }
     if (gemv_smem_bytes(kNW, rgi, 1, g.K, g.G, g.n_out) > 64 * 1024) return hipErrorInvalidValue;
+    if (g.xt_aux && g.K > 4 * 8 * kNW * 64) return hipErrorInvalidValue;   // transform works on register-held x
     const bool deep = g.K > 6144;
     switch (rgi) {
         case 4: return deep ? launch_group<4, 4>(g, acc, st) : launch_group<4, 2>(g, acc, st);
         case 2: return deep ? launch_group<2, 4>(g, acc, st) : launch_group<2, 2>(g, acc, st);
         default: return deep ? launch_group<1, 4>(g, acc, st) : launch_group<1, 2>(g, acc, st);
+    }
+}
+
+// ---- down_proj of the decode engine: x := silu(gate) * up fused into the staging, batch 1
+template <int RGI, int D>
+static hipError_t launch_silu(const GemvArgs& a, hipStream_t st) {
+    const size_t smem = gemv_smem_bytes(kNW, RGI, 1, a.K, a.G, a.n_out);
+    const dim3 grid(a.N / (4 * RGI)), block(kNW * 64);
+    if (a.n_out > 0) hipLaunchKernelGGL((gemv_w4_kernel<kNW, RGI, 1, D, true, false, 0, 2>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((gemv_w4_kernel<kNW, RGI, 1, D, false, false, 0, 2>), grid, block, smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st) {
+    const int rgs = a.N / 4;
+    int rgi = 4;
+    while (rgi > 1 && (rgs % rgi != 0 || rgs / rgi < 256)) rgi >>= 1;
+    if (a.n_out > 0 && rgi == 1 && (rgs & 1)) return hipErrorInvalidValue;
+    if (gemv_smem_bytes(kNW, rgi, 1, a.K, a.G, a.n_out) > 64 * 1024 || a.K > 4 * 8 * kNW * 64) return hipErrorInvalidValue;
+    const bool deep = a.K > 6144;
+    switch (rgi) {
+        case 4: return deep ? launch_silu<4, 4>(a, st) : launch_silu<4, 2>(a, st);
+        case 2: return deep ? launch_silu<2, 4>(a, st) : launch_silu<2, 2>(a, st);
+        default: return deep ? launch_silu<1, 4>(a, st) : launch_silu<1, 2>(a, st);
     }
 }
 

@@ -39,8 +39,12 @@ __host__ __device__ constexpr size_t gemv_smem_bytes(int NW, int RGI, int M, int
 //   acc += s * (P - A_c) + sz * B_c.
 // 5 integer ops + 4 dot2 per 8 weights instead of 13 + 4; weights are the exact q*s+sz (not rounded to fp16).
 // NW   waves per block (4 or 8); wave w owns the steps w, w+NW, ...
-template <int NW, int RGI, int M, int D, bool OUTL, bool XG, int ABL = 0>
+// XT   transform applied to x while it is staged (M == 1 only): 0 none, 1 RMSNorm (x * rsqrt(mean x^2 + eps) * gamma,
+//      a.xt_aux = gamma[K]), 2 SiLU-gate (silu(x) * up, a.xt_aux = up[K]).  Rounded to fp16 exactly like the
+//      stand-alone kernels in decode_aux.hip, so fusing does not change results.
+template <int NW, int RGI, int M, int D, bool OUTL, bool XG, int ABL = 0, int XT = 0>
 __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
+    static_assert(XT == 0 || (M == 1 && !XG), "x transforms are for the batch-1 decode engine");
     constexpr int kWaves = NW, kBlock = NW * 64;
     constexpr int LPS = 64 / RGI;        // lanes per row-group within the wave
     constexpr int KSTEP = 512 / RGI;     // k advanced per step
@@ -72,9 +76,15 @@ __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
     const int xvecs = xtotal / 8;
     u32x4 xst[XG ? 1 : 4];
     (void)xst;
+    u32x4 ast[XT ? 4 : 1];
+    (void)ast;
     if (!XG) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) xst[p] = *(const u32x4*)(a.x + (size_t)min(p * kBlock + tid, xvecs - 1) * 8);
+        for (int p = 0; p < 4; ++p) {
+            const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
+            xst[p] = *(const u32x4*)(a.x + e);
+            if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
+        }
     }
     constexpr int NIR = (RGI == 1) ? 4 : ROWS / 2;                    // interleaved rows this block touches
     const int slab_vecs = OUTL ? NIR * (2 * a.n_out) / 8 : 0;         // 16-byte pieces of them
@@ -108,6 +118,47 @@ __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
     for (int d = 0; d < D; ++d) {
         issue(ring[d], wave + d * kWaves);
         __builtin_amdgcn_sched_barrier(0);   // keep slot order = issue order: slot 0 must be the oldest load
+    }
+
+    // ---- 2b. optional x transform on the register-held vectors (covers K <= 4 * 8 * block threads)
+    if (XT == 1) {
+        float ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p * kBlock + tid < xvecs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const h2 t = as_h2(xst[p][j]);
+                    ss += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
+                }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) tot += red[w];
+        const float rs = rsqrtf(tot / (float)a.K + a.xt_eps);
+        __syncthreads();   // red is reused by the final reduction
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h2 t = as_h2(xst[p][j]), gm = as_h2(ast[p][j]);
+                xst[p][j] = as_u32(h2{(f16)((float)t[0] * rs * (float)gm[0]), (f16)((float)t[1] * rs * (float)gm[1])});
+            }
+        }
+    } else if (XT == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
+                const float g0 = (float)t[0], g1 = (float)t[1];
+                xst[p][j] = as_u32(h2{(f16)(g0 / (1.f + __expf(-g0)) * (float)u[0]), (f16)(g1 / (1.f + __expf(-g1)) * (float)u[1])});
+            }
+        }
     }
 
     // ---- 3. stage scales, x' (+ per-chunk sums) and the outlier slab into LDS
@@ -309,14 +360,14 @@ __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
     }
 }
 
-template <int NW, int RGI, int M, int D, bool OUTL, bool XG, int ABL = 0>
+template <int NW, int RGI, int M, int D, bool OUTL, bool XG, int ABL = 0, int XT = 0>
 __global__ __launch_bounds__(NW * 64) void gemv_w4_kernel(GemvArgs a) {
-    gemv_w4_body<NW, RGI, M, D, OUTL, XG, ABL>(a, blockIdx.x);
+    gemv_w4_body<NW, RGI, M, D, OUTL, XG, ABL, XT>(a, blockIdx.x);
 }
 
 // Several linears that share the same input (q/k/v, gate/up) in ONE launch: block ranges [blk_end[p-1], blk_end[p])
 // belong to part p.  Same K / group / n_out / batch for all parts; N may differ.
-template <int NW, int RGI, int M, int D, bool OUTL>
+template <int NW, int RGI, int M, int D, bool OUTL, int XT = 0>
 __global__ __launch_bounds__(NW * 64) void gemv_w4_group_kernel(GemvGroupArgs g) {
     int p = 0, blk = blockIdx.x;
     if (blk >= g.blk_end[0]) { p = 1; blk -= g.blk_end[0]; if (blockIdx.x >= (unsigned)g.blk_end[1]) { p = 2; blk = blockIdx.x - g.blk_end[1]; } }
@@ -335,7 +386,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_group_kernel(GemvGroupArgs g)
     a.G = g.G;
     a.n_out = g.n_out;
     a.gshift = g.gshift;
-    gemv_w4_body<NW, RGI, M, D, OUTL, false, 0>(a, blk);
+    a.xt_aux = g.xt_aux;
+    a.xt_eps = g.xt_eps;
+    gemv_w4_body<NW, RGI, M, D, OUTL, false, 0, XT>(a, blk);
 }
 
 }  // namespace qeft

@@ -60,6 +60,8 @@ struct GemvArgs {
     f16* y;
     int N, K, G, n_out;
     int gshift;  // log2(G) for power-of-two groups, 31 when G == K (single group)
+    const f16* xt_aux;   // x transform operand (gamma or up), see gemv_w4_kernel.h XT
+    float xt_eps;
 };
 
 struct GemvGroupArgs {
@@ -73,6 +75,8 @@ struct GemvGroupArgs {
     int N[3];
     int blk_end[3];
     int K, G, n_out, gshift;
+    const f16* xt_aux;
+    float xt_eps;
 };
 
 __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }

@@ -6,8 +6,8 @@ tree (same attribute names as HF: model.layers[i].self_attn.{q,k,v,o}_proj, mlp.
 synthetic packed weights, and a `DecodeEngine` that runs one token as a fixed sequence of
 C-ABI launches on static buffers so the whole step can be captured into one hipGraph:
 
-    rmsnorm -> [q|k|v] grouped GEMV -> rotary + KV append + attention -> o_proj GEMV (+gather, +residual)
-            -> rmsnorm -> [gate|up] grouped GEMV -> silu*mul -> down_proj GEMV (+residual)
+    [q|k|v] grouped GEMV (input RMSNorm fused) -> rotary + KV append + attention -> o_proj GEMV (+gather, +residual)
+            -> [gate|up] grouped GEMV (post-attention RMSNorm fused) -> down_proj GEMV (silu*mul fused, +residual)
 
 `QuantLlama.forward_dense_reference` is a plain fp32 PyTorch implementation over the dense dequantised weights,
 used by the tests and by `eval_nll` as the parity target ("PPL vs reference" on synthetic weights).
@@ -56,9 +56,11 @@ def tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=512, max_seq=
 # synthetic packed layers: W ~ N(0, 0.02^2), per-group asymmetric min-max INT4, last n_out
 # columns kept fp16
 # ----------------------------------------------------------------------------------------------------
-def synthetic_quantlinear(name, in_f, out_f, n_out, group_size, seed, device, outlieridx=None):
-    gen = torch.Generator(device="cpu").manual_seed(seed)
-    w = (torch.randn(out_f, in_f, generator=gen, dtype=torch.float32) * 0.02).to(device).half()
+def synthetic_quantlinear(name, in_f, out_f, n_out, group_size, seed, device, outlieridx=None, fast_init=False):
+    # CPU generator: identical weights on every device / rank for a given seed
+    gdev = "cpu" if (torch.device(device).type == "cpu" or not fast_init) else device
+    gen = torch.Generator(device=gdev).manual_seed(seed)
+    w = (torch.randn(out_f, in_f, generator=gen, dtype=torch.float32, device=gdev) * 0.02).to(device).half()
     scale, zero = minmax_params(w, group_size)
     wq = fake_quantize(w, scale, zero, group_size).half()
     if n_out > 0:
@@ -92,7 +94,8 @@ class _Inner(nn.Module):
 class QuantLlama(nn.Module):
     """Module tree with HF's attribute names; every decoder linear is a packed QuantLinear."""
 
-    def __init__(self, shape: LlamaShape, device="cuda:0", seed=0):
+    def __init__(self, shape: LlamaShape, device="cuda:0", seed=0, fast_init=False):
+        """fast_init: draw the synthetic weights with the device generator (much faster for 7B/13B shapes)."""
         super().__init__()
         assert shape.head_dim == 128, "the decode attention kernel is built for head_dim 128"
         self.shape = shape
@@ -113,16 +116,16 @@ class QuantLlama(nn.Module):
             L.mlp = _Mlp()
             pre = f"model.layers.{li}."
             sd = 1000 * li + seed * 7919
-            L.self_attn.q_proj = synthetic_quantlinear(pre + "self_attn.q_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 0, device)
-            L.self_attn.k_proj = synthetic_quantlinear(pre + "self_attn.k_proj", s.hidden, kv, s.n_out, s.group_size, sd + 1, device)
-            L.self_attn.v_proj = synthetic_quantlinear(pre + "self_attn.v_proj", s.hidden, kv, s.n_out, s.group_size, sd + 2, device)
+            L.self_attn.q_proj = synthetic_quantlinear(pre + "self_attn.q_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 0, device, fast_init=fast_init)
+            L.self_attn.k_proj = synthetic_quantlinear(pre + "self_attn.k_proj", s.hidden, kv, s.n_out, s.group_size, sd + 1, device, fast_init=fast_init)
+            L.self_attn.v_proj = synthetic_quantlinear(pre + "self_attn.v_proj", s.hidden, kv, s.n_out, s.group_size, sd + 2, device, fast_init=fast_init)
             # o_proj has its OWN outlier columns (per layer, reorder.py:38-46) -> runtime gather of its input
             g2 = torch.Generator(device="cpu").manual_seed(sd + 99)
             oidx = torch.randperm(s.hidden, generator=g2)[:max(s.n_out, 1)].sort().values.to(torch.int32) if s.n_out else None
-            L.self_attn.o_proj = synthetic_quantlinear(pre + "self_attn.o_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 3, device, oidx)
-            L.mlp.gate_proj = synthetic_quantlinear(pre + "mlp.gate_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 4, device)
-            L.mlp.up_proj = synthetic_quantlinear(pre + "mlp.up_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 5, device)
-            L.mlp.down_proj = synthetic_quantlinear(pre + "mlp.down_proj", s.inter, s.hidden, s.n_out, s.group_size, sd + 6, device)
+            L.self_attn.o_proj = synthetic_quantlinear(pre + "self_attn.o_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 3, device, oidx, fast_init=fast_init)
+            L.mlp.gate_proj = synthetic_quantlinear(pre + "mlp.gate_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 4, device, fast_init=fast_init)
+            L.mlp.up_proj = synthetic_quantlinear(pre + "mlp.up_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 5, device, fast_init=fast_init)
+            L.mlp.down_proj = synthetic_quantlinear(pre + "mlp.down_proj", s.inter, s.hidden, s.n_out, s.group_size, sd + 6, device, fast_init=fast_init)
             L.input_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
             L.post_attention_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
             layers.append(L)
@@ -194,27 +197,44 @@ def _ptr_array(tensors):
 
 
 class DecodeEngine:
-    """One decode token = a fixed list of C-ABI launches on static buffers (hipGraph-capturable)."""
+    """One decode token = a fixed list of C-ABI launches on static buffers (hipGraph-capturable).
 
-    def __init__(self, model: QuantLlama, use_graph=True):
+    With `tp_group` (world size P > 1) every quantized linear is row-sharded over the group (sharded.py): each rank
+    streams 1/P of the weights and one all-gather per linear (4 per layer: q|k|v, o_proj, silu(gate)*up, down_proj)
+    rebuilds the activations; everything else is replicated.
+    """
+
+    def __init__(self, model: QuantLlama, use_graph=True, tp_group=None):
+        import torch.distributed as dist
+        from .sharded import shard_quantlinear
         self.m = model
         s = model.shape
         dev = model.lm_head.weight.device
         self.dev = dev
         self.lib = _lib.lib()
+        self.tp_group = tp_group
+        self.P = dist.get_world_size(tp_group) if tp_group is not None else 1
+        self.rank = dist.get_rank(tp_group) if tp_group is not None else 0
+        P = self.P
         f16 = dict(dtype=torch.float16, device=dev)
         self.tok = torch.zeros(1, dtype=torch.long, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.h = torch.zeros(s.hidden, **f16)
+        self.hbuf = [torch.zeros(s.hidden, **f16), torch.zeros(s.hidden, **f16)]
         self.xn = torch.zeros(s.hidden, **f16)
         kvd = s.n_kv_heads * s.head_dim
+        self.hs, self.kvs, self.its = s.hidden // P, kvd // P, s.inter // P
         self.q = torch.zeros(s.hidden, **f16)
         self.k = torch.zeros(kvd, **f16)
         self.v = torch.zeros(kvd, **f16)
         self.att = torch.zeros(s.hidden, **f16)
-        self.gate = torch.zeros(s.inter, **f16)
-        self.up = torch.zeros(s.inter, **f16)
         self.act = torch.zeros(s.inter, **f16)
+        # local (per-rank) slices; with P == 1 they alias the full buffers
+        self.qkv_loc = torch.zeros(self.hs + 2 * self.kvs, **f16) if P > 1 else None
+        self.qkv_all = torch.zeros(P, self.hs + 2 * self.kvs, **f16) if P > 1 else None
+        self.h_loc = torch.zeros(self.hs, **f16) if P > 1 else None
+        self.gate_loc = torch.zeros(self.its, **f16)
+        self.up_loc = torch.zeros(self.its, **f16)
+        self.act_loc = torch.zeros(self.its, **f16) if P > 1 else self.act
         self.hn = torch.zeros(1, s.hidden, **f16)
         self.logits = torch.zeros(1, s.vocab, **f16)
         self.kc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
@@ -222,81 +242,140 @@ class DecodeEngine:
         self.greedy = False
         self.graph = None
         self.use_graph = use_graph
-        # per-layer argument packs (host arrays of device pointers must stay alive)
+        # per-layer local linears + argument packs (host arrays of device pointers must stay alive)
+        self.lin = []
         self.packs = []
         for L in model.model.layers:
             a, mlp = L.self_attn, L.mlp
-            qkv = [a.q_proj, a.k_proj, a.v_proj]
-            gu = [mlp.gate_proj, mlp.up_proj]
+            names = dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.o_proj, g=mlp.gate_proj, u=mlp.up_proj, d=mlp.down_proj)
+            if P > 1:
+                names = {kk: shard_quantlinear(vv, self.rank, P).to(dev) for kk, vv in names.items()}
+            self.lin.append(names)
+            qkv = [names["q"], names["k"], names["v"]]
+            gu = [names["g"], names["u"]]
             no = s.n_out
+            if P > 1:
+                qkv_y = [self.qkv_loc[:self.hs], self.qkv_loc[self.hs:self.hs + self.kvs], self.qkv_loc[self.hs + self.kvs:]]
+            else:
+                qkv_y = [self.q, self.k, self.v]
             self.packs.append(dict(
                 qkv=(_ptr_array([l.qweight for l in qkv]), _ptr_array([l.scales for l in qkv]),
                      _ptr_array([l.scaled_zeros for l in qkv]),
                      _ptr_array([l.oweight_interleaved for l in qkv]) if no else None,
-                     _ptr_array([self.q, self.k, self.v]), (ctypes.c_int * 3)(s.hidden, kvd, kvd)),
+                     _ptr_array(qkv_y), (ctypes.c_int * 3)(self.hs, self.kvs, self.kvs)),
                 gu=(_ptr_array([l.qweight for l in gu]), _ptr_array([l.scales for l in gu]),
                     _ptr_array([l.scaled_zeros for l in gu]),
                     _ptr_array([l.oweight_interleaved for l in gu]) if no else None,
-                    _ptr_array([self.gate, self.up]), (ctypes.c_int * 2)(s.inter, s.inter)),
+                    _ptr_array([self.gate_loc, self.up_loc]), (ctypes.c_int * 2)(self.its, self.its)),
             ))
+
+    @property
+    def h(self):
+        return self.hbuf[0]
 
     def reset(self):
         self.pos.zero_()
 
+    def weight_bytes_per_token(self):
+        """Algorithmic HBM bytes of the quantized linears one token streams on THIS rank (SURVEY.md §8d formula)."""
+        tot = 0
+        for names in self.lin:
+            for l in names.values():
+                n, k, r, g = l.outfeatures, l.infeatures, l.outlierfeatures, l.group_size
+                tot += n * (k - r) // 2 + 2 * (k // g) * n * 2 + n * r * 2 + 2 * k + 2 * n
+        return tot
+
     # -- the launch sequence ---------------------------------------------------------------------------
     @torch.no_grad()
-    def _launch_token(self):
-        s, lib, ck = self.m.shape, self.lib, _lib.check
+    def _launch_token(self, linears_only=False):
+        import torch.distributed as dist
+        s, lib, ck, P = self.m.shape, self.lib, _lib.check, self.P
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        torch.index_select(self.m.model.embed_tokens.weight, 0, self.tok, out=self.h.view(1, -1))
+        h, h2 = self.hbuf
+        if not linears_only:
+            torch.index_select(self.m.model.embed_tokens.weight, 0, self.tok, out=h.view(1, -1))
         g, no = s.group_size, s.n_out
+        r0 = self.rank * self.hs
         for li, L in enumerate(self.m.model.layers):
-            a, mlp, pk = L.self_attn, L.mlp, self.packs[li]
-            ck(lib.qeft_rmsnorm(self.h.data_ptr(), None, L.input_layernorm.data_ptr(), None, self.xn.data_ptr(), 1,
-                                s.hidden, s.rms_eps, st))
+            lin, pk = self.lin[li], self.packs[li]
+            # input_layernorm is fused into the q|k|v launch (x is normalised while it is staged)
             qw, sc, sz, ow, ys, ns = pk["qkv"]
-            ck(lib.qeft_gemv_w4_group(self.xn.data_ptr(), 3, qw, sc, sz, ow, None, ys, ns, s.hidden, g, no, st))
-            ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
-                                         self.m.rope_cos.data_ptr(), self.m.rope_sin.data_ptr(),
-                                         self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
-                                         self.att.data_ptr(), s.n_heads, s.n_kv_heads, s.max_seq, st))
-            o = a.o_proj
+            ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None,
+                                      ys, ns, s.hidden, g, no, st))
+            if P > 1:
+                dist.all_gather_into_tensor(self.qkv_all.view(-1), self.qkv_loc, group=self.tp_group)
+                self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
+                self.k.view(P, self.kvs).copy_(self.qkv_all[:, self.hs:self.hs + self.kvs])
+                self.v.view(P, self.kvs).copy_(self.qkv_all[:, self.hs + self.kvs:])
+            if not linears_only:
+                ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
+                                             self.m.rope_cos.data_ptr(), self.m.rope_sin.data_ptr(),
+                                             self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                             self.att.data_ptr(), s.n_heads, s.n_kv_heads, s.max_seq, st))
+            o = lin["o"]
             ids = o.reorder_ids32.data_ptr() if hasattr(o, "reorder_ids32") else None
-            ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
-                                      o.scaled_zeros.data_ptr(), o.oweight_interleaved.data_ptr() if no else None,
-                                      None, ids, self.h.data_ptr(), self.h.data_ptr(), 1, s.hidden, s.hidden, g, no, st))
-            ck(lib.qeft_rmsnorm(self.h.data_ptr(), None, L.post_attention_layernorm.data_ptr(), None,
-                                self.xn.data_ptr(), 1, s.hidden, s.rms_eps, st))
+            ow_o = o.oweight_interleaved.data_ptr() if no else None
+            if P > 1:
+                ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
+                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h[r0:r0 + self.hs].data_ptr(),
+                                          self.h_loc.data_ptr(), 1, self.hs, s.hidden, g, no, st))
+                dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
+                h, h2 = h2, h
+            else:
+                ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
+                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h.data_ptr(), h.data_ptr(), 1,
+                                          s.hidden, s.hidden, g, no, st))
             qw, sc, sz, ow, ys, ns = pk["gu"]
-            ck(lib.qeft_gemv_w4_group(self.xn.data_ptr(), 2, qw, sc, sz, ow, None, ys, ns, s.hidden, g, no, st))
-            ck(lib.qeft_silu_mul(self.gate.data_ptr(), self.up.data_ptr(), self.act.data_ptr(), s.inter, st))
-            d = mlp.down_proj
-            ck(lib.qeft_gemv_w4_fused(self.act.data_ptr(), d.qweight.data_ptr(), d.scales.data_ptr(),
-                                      d.scaled_zeros.data_ptr(), d.oweight_interleaved.data_ptr() if no else None,
-                                      None, None, self.h.data_ptr(), self.h.data_ptr(), 1, s.hidden, s.inter, g, no, st))
-        ck(lib.qeft_rmsnorm(self.h.data_ptr(), None, self.m.model.norm.data_ptr(), None, self.hn.data_ptr(), 1,
+            ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz,
+                                      ow, None, ys, ns, s.hidden, g, no, st))
+            if P > 1:
+                if not linears_only:
+                    ck(lib.qeft_silu_mul(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), self.act_loc.data_ptr(),
+                                         self.its, st))
+                dist.all_gather_into_tensor(self.act, self.act_loc, group=self.tp_group)
+            d = lin["d"]
+            ow_d = d.oweight_interleaved.data_ptr() if no else None
+            if P > 1:
+                ck(lib.qeft_gemv_w4_fused(self.act.data_ptr(), d.qweight.data_ptr(), d.scales.data_ptr(),
+                                          d.scaled_zeros.data_ptr(), ow_d, None, None, h[r0:r0 + self.hs].data_ptr(),
+                                          self.h_loc.data_ptr(), 1, self.hs, s.inter, g, no, st))
+                dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
+                h, h2 = h2, h
+            else:
+                # silu(gate) * up is formed while down_proj stages its input
+                ck(lib.qeft_gemv_w4_silu(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), d.qweight.data_ptr(),
+                                         d.scales.data_ptr(), d.scaled_zeros.data_ptr(), ow_d, None, h.data_ptr(),
+                                         h.data_ptr(), s.hidden, s.inter, g, no, st))
+        if linears_only:
+            return
+        # an even number of buffer swaps per token: the result is back in hbuf[0]
+        ck(lib.qeft_rmsnorm(h.data_ptr(), None, self.m.model.norm.data_ptr(), None, self.hn.data_ptr(), 1,
                             s.hidden, s.rms_eps, st))
         torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
         if self.greedy:
             torch.argmax(self.logits, dim=-1, out=self.tok)
         self.pos.add_(1)
 
-    def capture(self):
+    def capture(self, linears_only=False):
         """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires)."""
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         pos0, tok0 = self.pos.clone(), self.tok.clone()
         with torch.cuda.stream(side):
-            self._launch_token()
+            self._launch_token(linears_only)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         self.pos.copy_(pos0)
         self.tok.copy_(tok0)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._launch_token()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._launch_token(linears_only)
         self.pos.copy_(pos0)
         self.tok.copy_(tok0)
+        if linears_only:
+            return graph
+        self.graph = graph
+        return graph
 
     def step(self):
         """Run one token: consumes self.tok at position self.pos, leaves logits (and, if greedy, the next token)."""

@@ -1,0 +1,56 @@
+"""Row-sharded QuantLinear over the GPUs of one node (no reference counterpart).
+
+Output rows of W[N, K] are independent, so rank r keeps rows [r*N/P, (r+1)*N/P) of every packed buffer
+(multiples of 8 rows keep the 4-row nibble interleave and the 8-row outlier interleave intact), computes its slice
+of y with the same kernels, and ONE collective per linear (all-gather of y[m, N/P] over RCCL/xGMI; the payload is
+m*N*2 bytes, latency-bound at decode) rebuilds the full activation.  x is replicated.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .qlinear import QuantLinear
+
+
+def shard_bounds(n, rank, world):
+    assert n % (8 * world) == 0, f"out_features {n} must be a multiple of 8*world_size ({8 * world})"
+    per = n // world
+    return rank * per, (rank + 1) * per
+
+
+def shard_quantlinear(ql: QuantLinear, rank: int, world: int) -> QuantLinear:
+    """Rows [n0, n1) of a packed QuantLinear as a stand-alone QuantLinear (shares no storage with the original)."""
+    n0, n1 = shard_bounds(ql.outfeatures, rank, world)
+    out = QuantLinear(ql.bits, ql.infeatures, n1 - n0, ql.bias is not None, ql.dtype, ql.outlierfeatures,
+                      ql.group_size, getattr(ql, "reorder", False), ql.name)
+    out.qweight = ql.qweight[n0 // 4:n1 // 4].clone()
+    out.scales = ql.scales[:, n0:n1].contiguous()
+    out.scaled_zeros = ql.scaled_zeros[:, n0:n1].contiguous()
+    if ql.bias is not None:
+        out.bias = ql.bias[n0:n1].clone()
+    if ql.outlierfeatures > 0:
+        out.oweight = ql.oweight.detach()[n0:n1].clone()
+        out.oweight_interleaved = ql.oweight_interleaved[n0 // 2:n1 // 2].clone()
+        out.outlieridx = ql.outlieridx.clone()
+    out.fused = ql.fused
+    out.set_kernel(getattr(ql, "training", False))
+    return out
+
+
+class ShardedQuantLinear(nn.Module):
+    """Drop-in for a QuantLinear inside a tensor-parallel group: local rows + all-gather of the outputs."""
+
+    def __init__(self, full: QuantLinear, group=None):
+        super().__init__()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.outfeatures = full.outfeatures
+        self.infeatures = full.infeatures
+        self.local = shard_quantlinear(full, self.rank, self.world)
+
+    def forward(self, x):
+        y_loc = self.local(x).contiguous()
+        parts = [torch.empty_like(y_loc) for _ in range(self.world)]
+        dist.all_gather(parts, y_loc, group=self.group)
+        return torch.cat(parts, dim=-1)

@@ -103,7 +103,7 @@ def test_grouped_gemv_equals_separate_launches(ns, k, r):
             a[i] = t.data_ptr()
         return a
     _lib.check(_lib.lib().qeft_gemv_w4_group(
-        x.data_ptr(), len(ns), arr([l["qweight"] for l in layers]), arr([l["scales"] for l in layers]),
+        x.data_ptr(), None, 0.0, len(ns), arr([l["qweight"] for l in layers]), arr([l["scales"] for l in layers]),
         arr([l["scaled_zeros"] for l in layers]), arr([l["oweight_interleaved"] for l in layers]) if r else None, None,
         arr(ys), (ctypes.c_int * len(ns))(*ns), k, g, r, _st()))
     for l, n, y in zip(layers, ns, ys):
@@ -149,3 +149,57 @@ def test_decode_engine_greedy_graph_equals_eager():
             toks.append(int(eng.tok.item()))
         seqs.append(toks)
     assert seqs[0] == seqs[1]
+
+
+def _arr(ts):
+    a = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        a[i] = t.data_ptr()
+    return a
+
+
+@pytest.mark.parametrize("ns,k", [((4096, 4096, 4096), 4096), ((11008, 11008), 4096), ((256, 256), 512)])
+def test_fused_rmsnorm_group_equals_unfused(ns, k):
+    """RMSNorm folded into the grouped GEMV's x staging == qeft_rmsnorm followed by the grouped GEMV, bit for bit."""
+    from qeft_amd import _lib
+    lib, r, g = _lib.lib(), 128, 128
+    layers = [layer_to_torch(O.make_layer(n, k, r, g, seed=20 + i), DEV) for i, n in enumerate(ns)]
+    torch.manual_seed(5)
+    x = (torch.randn(1, k, device=DEV) * 2).half()
+    gamma = (1 + 0.1 * torch.randn(k, device=DEV)).half()
+    xn = torch.empty_like(x)
+    y0 = [torch.empty(1, n, device=DEV, dtype=torch.float16) for n in ns]
+    y1 = [torch.empty(1, n, device=DEV, dtype=torch.float16) for n in ns]
+    packs = (_arr([l["qweight"] for l in layers]), _arr([l["scales"] for l in layers]),
+             _arr([l["scaled_zeros"] for l in layers]), _arr([l["oweight_interleaved"] for l in layers]))
+    nn_ = (ctypes.c_int * len(ns))(*ns)
+    _lib.check(lib.qeft_rmsnorm(x.data_ptr(), None, gamma.data_ptr(), None, xn.data_ptr(), 1, k, 1e-5, _st()))
+    _lib.check(lib.qeft_gemv_w4_group(xn.data_ptr(), None, 0.0, len(ns), *packs, None, _arr(y0), nn_, k, g, r, _st()))
+    _lib.check(lib.qeft_gemv_w4_group(x.data_ptr(), gamma.data_ptr(), 1e-5, len(ns), *packs, None, _arr(y1), nn_, k, g,
+                                      r, _st()))
+    torch.cuda.synchronize()
+    for a, b in zip(y0, y1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,k", [(4096, 11008), (256, 512)])
+def test_fused_silu_down_equals_unfused(n, k):
+    from qeft_amd import _lib
+    lib, r, g = _lib.lib(), 128, 128
+    l = layer_to_torch(O.make_layer(n, k, r, g, seed=31), DEV)
+    torch.manual_seed(6)
+    gate = (torch.randn(k, device=DEV) * 2).half()
+    up = torch.randn(k, device=DEV).half()
+    res = torch.randn(1, n, device=DEV).half()
+    act = torch.empty_like(gate)
+    y0 = torch.empty(1, n, device=DEV, dtype=torch.float16)
+    y1 = torch.empty_like(y0)
+    _lib.check(lib.qeft_silu_mul(gate.data_ptr(), up.data_ptr(), act.data_ptr(), k, _st()))
+    _lib.check(lib.qeft_gemv_w4_fused(act.data_ptr(), l["qweight"].data_ptr(), l["scales"].data_ptr(),
+                                      l["scaled_zeros"].data_ptr(), l["oweight_interleaved"].data_ptr(), None, None,
+                                      res.data_ptr(), y0.data_ptr(), 1, n, k, g, r, _st()))
+    _lib.check(lib.qeft_gemv_w4_silu(gate.data_ptr(), up.data_ptr(), l["qweight"].data_ptr(), l["scales"].data_ptr(),
+                                     l["scaled_zeros"].data_ptr(), l["oweight_interleaved"].data_ptr(), None,
+                                     res.data_ptr(), y1.data_ptr(), n, k, g, r, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
