@@ -20,7 +20,7 @@
 //  * The fp16 outlier slice replaces the dead nibbles of the last n_out columns: lanes
 //    whose 32-k chunk lies there skip the INT4 load and read 128 B of oweight_interleaved.
 //  * Optional fusions (qeft_gemv_w4_fused): o_proj input gather through LDS, bias, residual.
-#include "gemv_w4_kernel.h"
+#include "gemv_w4_mfma.h"
 
 namespace qeft {
 
@@ -65,10 +65,67 @@ static hipError_t launch_r(const GemvArgs& a, int m, hipStream_t st) {
     }
 }
 
+// ---- MFMA formulation (gemv_w4_mfma.h): the production path for the Llama shapes
+static bool mfma_ok(int N, int K, int G, int n_out) {
+    return K % 128 == 0 && n_out % 128 == 0 && (G == 128 || G == K) && N % 16 == 0 && N / 16 >= 128;
+}
+
+template <int M, int D>
+static hipError_t launch_mfma(const GemvArgs& a, hipStream_t st) {
+    const size_t smem = gemv_mfma_smem_bytes(kNW, M, a.K, a.n_out);
+    const dim3 grid(a.N / 16), block(kNW * 64);
+    const bool outl = a.n_out > 0, xg = a.ids != nullptr;
+#define QEFT_LAUNCH(OUTL_, XG_)                                                                                        \
+    do {                                                                                                                \
+        auto kern = gemv_w4_mfma_kernel<kNW, M, D, OUTL_, XG_, 0, 0>;                                                    \
+        if (smem > 64 * 1024) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess) return e;                                                                              \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, grid, block, smem, st, a);                                                             \
+    } while (0)
+    if (xg) { if (outl) QEFT_LAUNCH(true, true); else QEFT_LAUNCH(false, true); }
+    else { if (outl) QEFT_LAUNCH(true, false); else QEFT_LAUNCH(false, false); }
+#undef QEFT_LAUNCH
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_mfma_m(const GemvArgs& a, int m, hipStream_t st) {
+    switch (m) {
+        case 1: return launch_mfma<1, D>(a, st);
+        case 2: return launch_mfma<2, D>(a, st);
+        case 3: return launch_mfma<3, D>(a, st);
+        case 4: return launch_mfma<4, D>(a, st);
+        case 5: return launch_mfma<5, D>(a, st);
+        case 6: return launch_mfma<6, D>(a, st);
+        default: return launch_mfma<7, D>(a, st);
+    }
+}
+
+// ring depth (steps in flight per wave), measured with tools/gemv_lab.hip: short rows want 2, long rows 6
+static int mfma_depth(int K) { return K > 6144 ? 6 : 2; }
+
 // Row-groups per wave-load: 4 (16 rows per block) when that still gives >= 1 block per CU, fewer for small
 // (e.g. row-sharded) layers so they still cover the 256 CUs.  The staged activations must fit the 160 KB LDS:
 // a batch that does not is processed in slices (the weights are then streamed once per slice).
 hipError_t gemv_w4_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
+    if (mfma_ok(a0.N, a0.K, a0.G, a0.n_out)) {
+        int mmax = m;
+        while (mmax > 1 && gemv_mfma_smem_bytes(kNW, mmax, a0.K, a0.n_out) > kMaxLds) --mmax;
+        if (gemv_mfma_smem_bytes(kNW, mmax, a0.K, a0.n_out) <= kMaxLds) {
+            for (int m0 = 0; m0 < m; m0 += mmax) {
+                const int mc = (m - m0 < mmax) ? m - m0 : mmax;
+                GemvArgs a = a0;
+                a.x = a0.x + (size_t)m0 * a0.K;
+                a.y = a0.y + (size_t)m0 * a0.N;
+                if (a0.residual) a.residual = a0.residual + (size_t)m0 * a0.N;
+                const hipError_t e = mfma_depth(a.K) == 6 ? launch_mfma_m<6>(a, mc, st) : launch_mfma_m<2>(a, mc, st);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+    }
     const int rgs = a0.N / 4;
     int rgi = 4;
     while (rgi > 1 && (rgs % rgi != 0 || rgs / rgi < 256)) rgi >>= 1;
@@ -108,7 +165,37 @@ static hipError_t launch_group(const GemvGroupArgs& g, int nblocks, hipStream_t 
     return hipGetLastError();
 }
 
+template <int D>
+static hipError_t launch_mfma_group(const GemvGroupArgs& g, int nblocks, hipStream_t st) {
+    const size_t smem = gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out);
+    const dim3 grid(nblocks), block(kNW * 64);
+    if (g.xt_aux) {
+        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 1>), grid, block, smem, st, g);
+        else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 1>), grid, block, smem, st, g);
+    } else {
+        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 0>), grid, block, smem, st, g);
+        else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 0>), grid, block, smem, st, g);
+    }
+    return hipGetLastError();
+}
+
 hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st) {
+    {
+        int ntot = 0;
+        bool ok = g.K <= 16384 && gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out) <= 64 * 1024;
+        for (int p = 0; p < nparts; ++p) {
+            ok = ok && g.N[p] % 16 == 0;
+            ntot += g.N[p];
+        }
+        if (ok && mfma_ok(ntot, g.K, g.G, g.n_out)) {
+            int acc = 0;
+            for (int p = 0; p < 3; ++p) {
+                if (p < nparts) acc += g.N[p] / 16;
+                g.blk_end[p] = acc;
+            }
+            return mfma_depth(g.K) == 6 ? launch_mfma_group<6>(g, acc, st) : launch_mfma_group<2>(g, acc, st);
+        }
+    }
     int total_rgs = 0;
     for (int p = 0; p < nparts; ++p) total_rgs += g.N[p] / 4;
     int rgi = 4;
@@ -143,7 +230,18 @@ static hipError_t launch_silu(const GemvArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int D>
+static hipError_t launch_mfma_silu(const GemvArgs& a, hipStream_t st) {
+    const size_t smem = gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out);
+    const dim3 grid(a.N / 16), block(kNW * 64);
+    if (a.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, true, false, 2, 0>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, false, false, 2, 0>), grid, block, smem, st, a);
+    return hipGetLastError();
+}
+
 hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st) {
+    if (mfma_ok(a.N, a.K, a.G, a.n_out) && a.K <= 16384 && gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out) <= 64 * 1024)
+        return mfma_depth(a.K) == 6 ? launch_mfma_silu<6>(a, st) : launch_mfma_silu<2>(a, st);
     const int rgs = a.N / 4;
     int rgi = 4;
     while (rgi > 1 && (rgs % rgi != 0 || rgs / rgi < 256)) rgi >>= 1;

@@ -1,0 +1,346 @@
+// Decode GEMV, MFMA formulation (the production path for K % 128 == 0, n_out % 128 == 0, G == 128 or G == K).
+//
+// Measured on MI355X (tools/gemv_lab.hip): with the VALU formulation (gemv_w4_kernel.h) the kernel is co-limited
+// by vector issue: ~50 VALU instructions per 16 weight bytes per lane is ~2 us of pure issue time on a 26 MB layer
+// that HBM can stream in ~4 us.  The matrix pipe is idle in a GEMV, and it takes exactly the fragment shape the
+// checkpoint already has:
+//
+//   v_mfma_f32_16x16x32_f16:  B operand lane L = (n = L & 15, k-group = L >> 4) holds 8 k-values of ONE column n
+//   checkpoint:               one u32 word holds 8 k-values of ONE weight row n
+//
+// One wave-wide 16 B/lane load = 16 rows (4 row-groups) x 128 k.  Lane L loads the 16 bytes of row (L & 15), 32-k
+// chunk (L >> 4); its 4 words are the B fragments of 4 MFMAs, which together contract the step's 128 k for all 16
+// rows and up to 16 batch rows at once — no cross-lane reduction, and batch 1..7 cost the same.
+// The A operand is x, staged in LDS in the matching k-order (dwords {w, w+4, w+8, w+12} of a 32-k chunk form
+// 16-byte slot w), one ds_read_b128 per MFMA.
+//
+// Arithmetic (identical to gemv_w4_kernel.h): nibbles become 1024+q / 1024+16q with one v_and_or_b32 each, x is
+// pre-multiplied by 1/16 where it meets high nibbles, and per step (= one quantisation group of 128 k)
+//   acc[m][n] += s[n] * (P[m][n] - A[m]) + sz[n] * B[m],   A = 1024 * sum x', B = sum x over the step's 128 k.
+// 5 integer ops per word + 1 MFMA + 1 LDS read per 8 weights per lane.
+#pragma once
+#include "gemv_w4_kernel.h"
+
+namespace qeft {
+
+__host__ __device__ constexpr size_t gemv_mfma_smem_bytes(int NW, int M, int K, int n_out) {
+    return (size_t)NW * 16 * M * 4 +                                   // red   [NW][M][16] f32
+           (n_out > 0 ? (size_t)16 * gemv_slab_stride(n_out) * 2 : 0) +  // slab  [16][n_out+8] f16 (permuted slots)
+           (size_t)(K / 128) * 16 * 4 +                                 // szl   [K/128][16] (s | sz << 16)
+           ((size_t)M * (K / 128) * 8 + 15) / 16 * 16 +                 // corr  [M][K/128] (A, B) f32
+           (size_t)M * K * 2;                                           // xs    [M][K] f16 (permuted slots, prescaled)
+}
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+
+template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
+__device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int blk) {
+    static_assert(XT == 0 || (M == 1 && !XG), "x transforms are for the batch-1 decode engine");
+    constexpr int kWaves = NW, kBlock = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* red = (float*)smem;
+    f16* slab = (f16*)(smem + NW * 16 * M * 4);
+    const int slab_stride = gemv_slab_stride(a.n_out);
+    uint32_t* szl = (uint32_t*)(slab + (OUTL ? 16 * slab_stride : 0));
+    const int nsteps = a.K / 128;
+    float* corr = (float*)(szl + nsteps * 16);
+    uint32_t* xs32 = (uint32_t*)((uint8_t*)corr + ((size_t)M * nsteps * 8 + 15) / 16 * 16);   // x' as dwords (k-pairs)
+    const f16* xs = (const f16*)xs32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nl = lane & 15, kc = lane >> 4;            // row within the block / 32-k chunk within the step
+    const int rg0 = blk * 4;
+    const int row0 = rg0 * 4;
+    const int kq = a.K - (OUTL ? a.n_out : 0);
+    const int nfull = kq / 128;                          // INT4 steps; steps [nfull, nsteps) are the fp16 outlier slice
+    const int nsw = (nfull - wave + kWaves - 1) / kWaves;
+    const bool per_channel = a.gshift == 31;
+
+    // ---- 1. oldest loads: x, the transform operand, the outlier slab, the scales
+    const int xtotal = M * a.K;
+    const int xvecs = xtotal / 8;
+    u32x4 xst[XG ? 1 : 4];
+    u32x4 ast[XT ? 4 : 1];
+    (void)xst;
+    (void)ast;
+    if (!XG) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
+            xst[p] = *(const u32x4*)(a.x + e);
+            if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
+        }
+    }
+    const int slab_vecs = OUTL ? 8 * (2 * a.n_out) / 8 : 0;           // 8 interleaved rows of 2*n_out halves
+    const f16* osrc = OUTL ? a.ow_il + (size_t)(rg0 >> 1) * 4 * (2 * a.n_out) : nullptr;
+    u32x4 ost = {0u, 0u, 0u, 0u};
+    if (OUTL) ost = *(const u32x4*)(osrc + (size_t)min(tid, slab_vecs - 1) * 8);
+    const int ngroups = per_channel ? 1 : nsteps;
+    const int szn = ngroups * 8;                                       // dwords of two adjacent rows
+    uint32_t sst[2], zst[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int i = min(p * kBlock + tid, szn - 1);
+        const uint32_t so = (uint32_t)(i >> 3) * (uint32_t)a.N + row0 + (i & 7) * 2;
+        sst[p] = (ABL & 1) ? 0x1c001c00u : *(const uint32_t*)(a.scales + so);
+        zst[p] = (ABL & 1) ? 0xa000a000u : *(const uint32_t*)(a.zeros + so);
+    }
+
+    // ---- 2. weight stream: ring of D steps per wave (steps wave, wave+NW, ...), branch-free, oldest first
+    const int s_last = max(wave + (nsw - 1) * kWaves, 0);
+    u32x4 ring[D];
+    const uint8_t* wbase = a.qw + (size_t)(rg0 + (nl >> 2)) * a.K * 2 + (kc >> 1) * 128 + (nl & 3) * 32 + (kc & 1) * 16;
+    auto issue = [&](u32x4& b, int s) {
+        s = min(s, s_last);
+        const uint32_t woff = min((uint32_t)s * 256u, (uint32_t)a.K * 2 - 256u);   // stays inside the row-group
+        b = __builtin_nontemporal_load((const u32x4*)(wbase + woff));
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        issue(ring[d], wave + d * kWaves);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- 2b. optional x transform on the register-held vectors
+    if (XT == 1) {
+        float ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p * kBlock + tid < xvecs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const h2 t = as_h2(xst[p][j]);
+                    ss += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
+                }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) tot += red[w];
+        const float rs = rsqrtf(tot / (float)a.K + a.xt_eps);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h2 t = as_h2(xst[p][j]), gm = as_h2(ast[p][j]);
+                xst[p][j] = as_u32(h2{(f16)((float)t[0] * rs * (float)gm[0]), (f16)((float)t[1] * rs * (float)gm[1])});
+            }
+    } else if (XT == 2) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
+                const float g0 = (float)t[0], g1 = (float)t[1];
+                xst[p][j] = as_u32(h2{(f16)(g0 / (1.f + __expf(-g0)) * (float)u[0]), (f16)(g1 / (1.f + __expf(-g1)) * (float)u[1])});
+            }
+    }
+
+    // ---- 3. stage scales, x' (+ per-step sums) and the outlier slab into LDS
+    for (int i = tid, p = 0; i < szn; i += kBlock, ++p) {
+        uint32_t sv = sst[0], zv = zst[0];
+        if (p == 1) { sv = sst[1]; zv = zst[1]; }
+        if (p >= 2) {
+            const uint32_t so = (uint32_t)(i >> 3) * (uint32_t)a.N + row0 + (i & 7) * 2;
+            sv = *(const uint32_t*)(a.scales + so);
+            zv = *(const uint32_t*)(a.zeros + so);
+        }
+        *(u32x2*)(szl + i * 2) = u32x2{__builtin_amdgcn_perm(zv, sv, 0x05040100u), __builtin_amdgcn_perm(zv, sv, 0x07060302u)};
+    }
+    {
+        const h2 k16th = {(f16)0.0625f, (f16)0.0625f};
+        for (int v = tid, p = 0; v < xvecs; v += kBlock, ++p) {
+            u32x4 xv;
+            const int e = v * 8;
+            const int bm = e / a.K, k = e - bm * a.K;
+            if (XG) {
+                f16 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = a.x[(size_t)bm * a.K + a.ids[k + j]];   // qlinear.py:275
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] = as_u32(h2{t[2 * j], t[2 * j + 1]});
+            } else {
+                xv = xst[0];
+                if (p == 1) xv = xst[1];
+                if (p == 2) xv = xst[2];
+                if (p == 3) xv = xst[3];
+                if (p >= 4) xv = *(const u32x4*)(a.x + (size_t)e);
+            }
+            float bsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bsum += (float)as_h2(xv[j])[0] + (float)as_h2(xv[j])[1];
+            const int q = (k >> 3) & 3;                       // quarter of the 32-k chunk
+            const bool hi = (q & 1) && (k < kq);              // k%32 in [8,16) or [24,32): meets the high nibbles
+            float asum = bsum;
+            if (hi) {
+                asum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const h2 t = as_h2(xv[j]) * k16th;
+                    xv[j] = as_u32(t);
+                    asum += (float)t[0] + (float)t[1];
+                }
+            }
+            // dword i of quarter q is natural dword 4q+i of the chunk -> slot i, position q
+            uint32_t* dst = xs32 + (size_t)(e >> 5) * 16 + q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i * 4] = xv[i];
+            // the 16 vectors of a 128-k step sit in 16 consecutive lanes
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                asum += __shfl_xor(asum, o);
+                bsum += __shfl_xor(bsum, o);
+            }
+            if ((v & 15) == 0) {
+                corr[(e >> 7) * 2] = 1024.f * asum;
+                corr[(e >> 7) * 2 + 1] = bsum;
+            }
+        }
+    }
+    if (OUTL) {
+        // pack_oweight layout (qlinear.py:70-79); a 16-byte piece = 4 columns (2 dwords) of rows blk*8+rr and +4.
+        uint32_t* slab32 = (uint32_t*)slab;
+        const int sstr = slab_stride / 2;   // dwords per slab row
+        for (int v = tid; v < slab_vecs; v += kBlock) {
+            const u32x4 ov = (v == tid) ? ost : *(const u32x4*)(osrc + (size_t)v * 8);
+            const int per_row = (2 * a.n_out) / 8;
+            const int ir = v / per_row, piece = v % per_row;
+            const int c32 = piece >> 3, d0 = (piece & 7) * 2;          // natural dwords d0, d0+1 of the chunk
+            const uint32_t lo[2] = {__builtin_amdgcn_perm(ov[1], ov[0], 0x05040100u), __builtin_amdgcn_perm(ov[3], ov[2], 0x05040100u)};
+            const uint32_t hi[2] = {__builtin_amdgcn_perm(ov[1], ov[0], 0x07060302u), __builtin_amdgcn_perm(ov[3], ov[2], 0x07060302u)};
+            const int lrow = (ir >> 2) * 8 + (ir & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int d = d0 + i;
+                const int pos = c32 * 16 + (d & 3) * 4 + (d >> 2);      // slot d%4, position d/4
+                slab32[lrow * sstr + pos] = lo[i];
+                slab32[(lrow + 4) * sstr + pos] = hi[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. steps
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};     // acc[j]: batch row m = 4*kc + j, weight row nl
+    uint32_t MAGIC = 0x64006400u;
+    asm volatile("" : "+v"(MAGIC));
+    const int am = min(nl, M - 1);         // A-operand row of this lane (rows >= M replicate row M-1, never stored)
+    const f16* xa = xs + (size_t)am * a.K + kc * 32;
+
+    auto consume = [&](const u32x4& wv, int s) {
+        if (ABL & 4) {
+            acc[0] += __builtin_bit_cast(float, wv[0] ^ wv[1] ^ wv[2] ^ wv[3]);
+            return;
+        }
+        f32x4 P0 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};   // two chains: MFMA latency is exposed at 2 waves/SIMD
+        const h8v* px = (const h8v*)(xa + (size_t)s * 128);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t v = wv[w], t = v >> 8;
+            const u32x4 bw = {(v & 0x000f000fu) | MAGIC, (v & 0x00f000f0u) | MAGIC, (t & 0x000f000fu) | MAGIC,
+                              (t & 0x00f000f0u) | MAGIC};
+            if (w & 1) P1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], __builtin_bit_cast(h8v, bw), P1, 0, 0, 0);
+            else P0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], __builtin_bit_cast(h8v, bw), P0, 0, 0, 0);
+        }
+        const h2 szp = as_h2(szl[(per_channel ? 0 : s) * 16 + nl]);
+        const float sf = (float)szp[0], zf = (float)szp[1];
+#pragma unroll
+        for (int j = 0; j < (M < 4 ? M : 4); ++j) {       // batch row m = 4*kc + j; rows >= M are never stored
+            const int m = min(4 * kc + j, M - 1);
+            const float2 ab = *(const float2*)(corr + ((size_t)m * nsteps + s) * 2);
+            acc[j] += sf * ((P0[j] + P1[j]) - ab.x) + zf * ab.y;
+        }
+    };
+
+    // fp16 outlier steps [nfull, nsteps): B fragments straight from the LDS slab (same slot order), no correction
+    if (OUTL) {
+        for (int s = nfull + ((wave - nfull) % kWaves + kWaves) % kWaves; s < nsteps; s += kWaves) {
+            const h8v* px = (const h8v*)(xa + (size_t)s * 128);
+            const h8v* pw = (const h8v*)(slab + (size_t)nl * slab_stride + (s - nfull) * 128 + kc * 32);
+            f32x4 P = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) P = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], pw[w], P, 0, 0, 0);
+            if (!(ABL & 4)) acc += P;
+        }
+    }
+
+    const int nrounds = max((nsw + D - 1) / D, 1);
+    for (int rd = 0; rd + 1 < nrounds; ++rd) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int si = rd * D + d;
+            consume(ring[d], wave + si * kWaves);
+            issue(ring[d], wave + (si + D) * kWaves);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const int si = (nrounds - 1) * D + d;
+        if (si < nsw) consume(ring[d], wave + si * kWaves);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- 5. combine the waves
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = 4 * kc + j;
+        if (m < M) red[(wave * M + m) * 16 + nl] = acc[j];
+    }
+    __syncthreads();
+    if (tid < 16 * M) {
+        const int m = tid >> 4, n = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) v += red[(w * M + m) * 16 + n];
+        const int orow = row0 + n;
+        if (a.bias) v += (float)a.bias[orow];
+        if (a.residual) v += (float)a.residual[(size_t)m * a.N + orow];
+        a.y[(size_t)m * a.N + orow] = (f16)v;
+    }
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Neighbouring row blocks share the 128-byte
+// lines of scales / scaled_zeros (4 blocks per line) and of oweight_interleaved, so give each XCD a contiguous range
+// of row blocks: the lines are then fetched into one L2 instead of four.  Speed only; any placement is correct.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_kernel(GemvArgs a) {
+    gemv_w4_mfma_body<NW, M, D, OUTL, XG, XT, ABL>(a, (ABL & 8) ? (int)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x));
+}
+
+template <int NW, int D, bool OUTL, int XT = 0>
+__global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupArgs g) {
+    const int gb = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int p = 0, blk = gb;
+    if (gb >= g.blk_end[0]) { p = 1; blk = gb - g.blk_end[0]; if (gb >= g.blk_end[1]) { p = 2; blk = gb - g.blk_end[1]; } }
+    GemvArgs a;
+    a.x = g.x;
+    a.qw = g.qw[p];
+    a.scales = g.scales[p];
+    a.zeros = g.zeros[p];
+    a.ow_il = g.ow_il[p];
+    a.bias = g.bias[p];
+    a.ids = nullptr;
+    a.residual = nullptr;
+    a.y = g.y[p];
+    a.N = g.N[p];
+    a.K = g.K;
+    a.G = g.G;
+    a.n_out = g.n_out;
+    a.gshift = g.gshift;
+    a.xt_aux = g.xt_aux;
+    a.xt_eps = g.xt_eps;
+    gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0>(a, blk);
+}
+
+}  // namespace qeft

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "gemv_w4_kernel.h"
+#include "gemv_w4_mfma.h"
 
 using namespace qeft;
 
@@ -48,11 +48,25 @@ void run_variant(const char* name, std::vector<Layer>& Ls, void* x, void* y, int
     size_t smem = gemv_smem_bytes(NW, RGI, 1, K, 128, 128);
     auto f = [&](int l) {
         GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l].qw, (const f16*)Ls[l].sc, (const f16*)Ls[l].sz, (const f16*)Ls[l].ow,
-                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7};
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f};
         hipLaunchKernelGGL(kern, dim3(N / (4 * RGI)), dim3(NW * 64), smem, 0, a);
     };
     float us = time_launches(20, L, f);
     printf("  %-20s NW=%d RGI=%d D=%d ABL=%2d : %7.2f us  %6.0f GB/s\n", name, NW, RGI, D, ABL, us, bytes / us / 1e3);
+}
+
+template <int NW, int D, int ABL>
+void run_mfma(const char* name, std::vector<Layer>& Ls, void* x, void* y, int N, int K, double bytes) {
+    const int L = (int)Ls.size();
+    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, 0, ABL>;
+    size_t smem = gemv_mfma_smem_bytes(NW, 1, K, 128);
+    auto f = [&](int l) {
+        GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l].qw, (const f16*)Ls[l].sc, (const f16*)Ls[l].sz, (const f16*)Ls[l].ow,
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f};
+        hipLaunchKernelGGL(kern, dim3(N / 16), dim3(NW * 64), smem, 0, a);
+    };
+    float us = time_launches(20, L, f);
+    printf("  %-20s MFMA NW=%d D=%d ABL=%2d : %7.2f us  %6.0f GB/s\n", name, NW, D, ABL, us, bytes / us / 1e3);
 }
 
 int main(int argc, char** argv) {
@@ -87,16 +101,17 @@ int main(int argc, char** argv) {
         void *x, *y; CK(hipMalloc(&x, K * 2)); CK(hipMemset(x, 0x3c, K * 2)); CK(hipMalloc(&y, N * 2));
         double bytes = (double)N * (K - 128) / 2 + 2.0 * (K / 128) * N * 2 + (double)N * 128 * 2 + 2 * K + 2 * N;
         printf("N=%d K=%d algorithmic bytes %.0f\n", N, K, bytes);
-        run_variant<4, 4, 8, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<4, 4, 4, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 4, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 2, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 6, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<8, 2, 4, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<8, 2, 2, 0>("full", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 4, 1>("no scale loads", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 4, 4>("no math", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 4, 5>("no math/scales", Ls, x, y, N, K, bytes);
+        run_variant<8, 4, 2, 0>("valu full", Ls, x, y, N, K, bytes);
+        run_variant<8, 4, 4, 0>("valu full", Ls, x, y, N, K, bytes);
+        run_mfma<8, 2, 0>("mfma full", Ls, x, y, N, K, bytes);
+        run_mfma<8, 4, 0>("mfma full", Ls, x, y, N, K, bytes);
+        run_mfma<8, 6, 0>("mfma full", Ls, x, y, N, K, bytes);
+        run_mfma<4, 4, 0>("mfma full", Ls, x, y, N, K, bytes);
+        run_mfma<8, 2, 8>("mfma no xcd remap", Ls, x, y, N, K, bytes);
+        run_mfma<8, 4, 8>("mfma no xcd remap", Ls, x, y, N, K, bytes);
+        run_mfma<8, 4, 1>("mfma no scale ld", Ls, x, y, N, K, bytes);
+        run_mfma<8, 4, 4>("mfma no math", Ls, x, y, N, K, bytes);
+        run_mfma<8, 4, 5>("mfma no math/sc", Ls, x, y, N, K, bytes);
         for (auto& l : Ls) { (void)hipFree(l.qw); (void)hipFree(l.sc); (void)hipFree(l.sz); (void)hipFree(l.ow); }
         (void)hipFree(x); (void)hipFree(y);
     }
