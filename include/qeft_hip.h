@@ -60,11 +60,18 @@ int qeft_gemv_w4_qeft(const void* x, const void* qweight, const void* scales, co
 /* Fused decode GEMV: everything QuantLinear.forward_* does around the kernel in one launch
  * (qeft/qlinear.py:244-330): optional input gather x[:, reorder_ids] (:275, int32 ids, NULL = none),
  * optional bias add (:268, NULL = none), optional residual add into y (y = acc + residual; NULL = none).
- * oweight_il may be NULL when n_out == 0. */
+ * oweight_il may be NULL when n_out == 0; sz_packed (see qeft_pack_scales) may be NULL. */
 int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                        const void* oweight_il, const void* bias, const int* reorder_ids,
-                       const void* residual, void* y, int m, int n, int k, int group_size, int n_out,
-                       qeft_stream_t stream);
+                       const void* residual, const void* sz_packed, void* y, int m, int n, int k, int group_size,
+                       int n_out, qeft_stream_t stream);
+
+/* Optional derived buffer for the decode GEMV (never part of the checkpoint): sz_packed int32 [N/16][K/g][16] with
+ * scale | scaled_zero << 16 per (row, group), so the scales of a 16-row block are one contiguous run.  Built once at
+ * load time (QuantLinear.set_kernel); entries that take `sz_packed` accept NULL and then read scales / scaled_zeros
+ * in their checkpoint layout.  group_size must be 128 or k; n % 16 == 0. */
+int qeft_pack_scales(const void* scales, const void* scaled_zeros, void* sz_packed, int n, int k, int group_size,
+                     qeft_stream_t stream);
 
 /* Prefill / fine-tune GEMM  y[M,N] = x[M,K] . Wdeq[N,K]^T  on MFMA, fp32 accumulate, fp16 out.
  * Replaces gemm_4bit(in_feats, kernel, scales, zeros) (qeft/kernel/quantization_new/gemm/gemm_cuda.cu:929-1033).
@@ -105,14 +112,14 @@ int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, q
  * fused into the projection that consumes it (K <= 16384). */
 int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
                        const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
-                       const void* const* oweight_il, const void* const* bias, void* const* y, const int* n, int k,
-                       int group_size, int n_out, qeft_stream_t stream);
+                       const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream);
 
 /* down_proj of the decode step in one launch: y = W . (silu(gate) * up) (+ bias) (+ residual), batch 1.
  * The activation is formed while x is staged, rounded to fp16 exactly like qeft_silu_mul (K <= 16384). */
 int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, const void* scales,
                       const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
-                      void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream);
+                      const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream);
 
 /* y = rmsnorm(x (+ add)) * gamma, fp32 statistics (role of layernorm_forward_cuda, qeft/kernel/layernorm/layernorm.cu:26-76).
  * If add != NULL the sum x + add is normalised and, if res_out != NULL, also written there (fused residual). */
@@ -124,10 +131,12 @@ int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_strea
 
 /* One decode token of one sequence: rotary on q/k at position *pos (device int), append k/v to the caches
  * [n_kv][max_seq][128] and compute softmax(q.K^T/sqrt(128)).V (role of single_query_attention,
- * qeft/kernel/attention/ft_attention.cpp:110-181, neox rotary).  head_dim is 128. cos/sin: fp32 [max_seq][64]. */
+ * qeft/kernel/attention/ft_attention.cpp:110-181, neox rotary).  head_dim is 128. cos/sin: fp32 [max_seq][64].
+ * out_pos (optional int32 [n_heads*128]): element i of the attention output is stored at out[out_pos[i]].  With
+ * out_pos = inverse of o_proj's reorder_ids the o_proj input gather (qlinear.py:275) costs nothing. */
 int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
-                          void* k_cache, void* v_cache, const int* pos, void* out, int n_heads, int n_kv_heads,
-                          int max_seq, qeft_stream_t stream);
+                          void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out, int n_heads,
+                          int n_kv_heads, int max_seq, qeft_stream_t stream);
 
 #ifdef __cplusplus
 }

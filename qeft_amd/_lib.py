@@ -17,17 +17,18 @@ SIGNATURES = {
     "qeft_last_hip_error": [],
     "qeft_gemv_w4": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_gemv_w4_qeft": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "qeft_gemv_w4_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemv_w4_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_pack_scales": [_p, _p, _p, _i, _i, _i, _p],
     "qeft_gemm_w4": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_dx": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_grad_oweight": [_p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_dequant_w4": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_pack_oweight": [_p, _p, _i, _i, _p],
-    "qeft_gemv_w4_group": [_p, _p, ctypes.c_float, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "qeft_gemv_w4_silu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "qeft_gemv_w4_group": [_p, _p, ctypes.c_float, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_gemv_w4_silu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_rmsnorm": [_p, _p, _p, _p, _p, _i, _i, ctypes.c_float, _p],
     "qeft_silu_mul": [_p, _p, _p, _i, _p],
-    "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
 }
 
 _lib = None

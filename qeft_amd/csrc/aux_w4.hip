@@ -44,6 +44,26 @@ __global__ __launch_bounds__(256) void pack_oweight_kernel(const f16* ow, f16* i
     il[((size_t)(n / 8) * 4 + n % 4) * (2 * R) + (j / 32) * 64 + (j % 32) * 2 + (n % 8) / 4] = ow[idx];
 }
 
+// Shadow of scales / scaled_zeros for the decode GEMV: out[(n/16)][g][n%16] = scale | scaled_zero << 16, so the 16
+// rows x all groups a block needs are ONE contiguous run instead of K/G strided 32-byte pieces.
+__global__ __launch_bounds__(256) void pack_scales_kernel(const uint16_t* scales, const uint16_t* zeros, uint32_t* out,
+                                                          int N, int ngroups) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)N * ngroups) return;
+    const int j = (int)(idx & 15);
+    const int g = (int)((idx >> 4) % ngroups);
+    const int b = (int)((idx >> 4) / ngroups);
+    const size_t src = (size_t)g * N + b * 16 + j;
+    out[idx] = (uint32_t)scales[src] | ((uint32_t)zeros[src] << 16);
+}
+
+hipError_t pack_scales_launch(const void* scales, const void* zeros, void* out, int N, int ngroups, hipStream_t st) {
+    const size_t total = (size_t)N * ngroups;
+    hipLaunchKernelGGL(pack_scales_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, st, (const uint16_t*)scales,
+                       (const uint16_t*)zeros, (uint32_t*)out, N, ngroups);
+    return hipGetLastError();
+}
+
 hipError_t dequant_w4_launch(const void* qw, const void* scales, const void* zeros, const void* ow, void* out, int N,
                              int K, int G, int n_out, hipStream_t st) {
     const size_t total = (size_t)(N / 4) * (K / 32 * 4);

@@ -13,11 +13,12 @@ hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, voi
                           float eps, hipStream_t st);
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
-                                   void* vc, const int* pos, void* out, int n_heads, int n_kv, int max_seq,
-                                   hipStream_t st);
+                                   void* vc, const int* pos, const int* out_pos, void* out, int n_heads, int n_kv,
+                                   int max_seq, hipStream_t st);
 hipError_t dequant_w4_launch(const void* qw, const void* scales, const void* zeros, const void* ow, void* out, int N,
                              int K, int G, int n_out, hipStream_t st);
 hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream_t st);
+hipError_t pack_scales_launch(const void* scales, const void* zeros, void* out, int N, int ngroups, hipStream_t st);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
@@ -63,9 +64,10 @@ const char* qeft_error_string(int code) {
     }
 }
 
-int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
-                       const void* oweight_il, const void* bias, const int* reorder_ids, const void* residual,
-                       void* y, int m, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+static int gemv_fused_impl(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                           const void* oweight_il, const void* bias, const int* reorder_ids, const void* residual,
+                           const void* sz_packed, void* y, int m, int n, int k, int group_size, int n_out,
+                           qeft_stream_t stream) {
     if (m < 1 || m > 7) return QEFT_ERR_BATCH;
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
@@ -86,22 +88,33 @@ int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, c
     a.n_out = n_out;
     a.xt_aux = nullptr;
     a.xt_eps = 0.f;
+    a.sz_blk = (const uint32_t*)sz_packed;
+    a.dbg = nullptr;
+    if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
     return finish(qeft::gemv_w4_dispatch(a, m, (hipStream_t)stream));
 }
 
+int qeft_gemv_w4_fused(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                       const void* oweight_il, const void* bias, const int* reorder_ids, const void* residual,
+                       const void* sz_packed, void* y, int m, int n, int k, int group_size, int n_out,
+                       qeft_stream_t stream) {
+    return gemv_fused_impl(x, qweight, scales, scaled_zeros, oweight_il, bias, reorder_ids, residual, sz_packed, y, m, n,
+                           k, group_size, n_out, stream);
+}
+
 int qeft_gemv_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, void* y, int m,
                  int n, int k, int group_size, qeft_stream_t stream) {
-    return qeft_gemv_w4_fused(x, qweight, scales, scaled_zeros, nullptr, nullptr, nullptr, nullptr, y, m, n, k,
-                              group_size, 0, stream);
+    return gemv_fused_impl(x, qweight, scales, scaled_zeros, nullptr, nullptr, nullptr, nullptr, nullptr, y, m, n, k,
+                           group_size, 0, stream);
 }
 
 int qeft_gemv_w4_qeft(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                       const void* oweight_il, void* y, int m, int n, int k, int group_size, int n_out,
                       qeft_stream_t stream) {
-    return qeft_gemv_w4_fused(x, qweight, scales, scaled_zeros, oweight_il, nullptr, nullptr, nullptr, y, m, n, k,
-                              group_size, n_out, stream);
+    return gemv_fused_impl(x, qweight, scales, scaled_zeros, oweight_il, nullptr, nullptr, nullptr, nullptr, y, m, n, k,
+                           group_size, n_out, stream);
 }
 
 int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
@@ -147,6 +160,15 @@ int qeft_dequant_w4(const void* qweight, const void* scales, const void* scaled_
                                           (hipStream_t)stream));
 }
 
+int qeft_pack_scales(const void* scales, const void* scaled_zeros, void* sz_packed, int n, int k, int group_size,
+                     qeft_stream_t stream) {
+    if (n <= 0 || n % 16 != 0 || k <= 0 || group_size <= 0 || k % group_size != 0) return QEFT_ERR_SHAPE;
+    if (group_size != 128 && group_size != k) return QEFT_ERR_GROUP;   // what the MFMA decode GEMV consumes
+    if (!scales || !scaled_zeros || !sz_packed) return QEFT_ERR_NULL;
+    if (!aligned16(sz_packed)) return QEFT_ERR_ALIGN;
+    return finish(qeft::pack_scales_launch(scales, scaled_zeros, sz_packed, n, k / group_size, (hipStream_t)stream));
+}
+
 int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, qeft_stream_t stream) {
     if (n <= 0 || n % 8 != 0 || n_out <= 0 || n_out % 32 != 0) return QEFT_ERR_SHAPE;
     if (!oweight || !oweight_il) return QEFT_ERR_NULL;
@@ -155,8 +177,8 @@ int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, q
 
 int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
                        const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
-                       const void* const* oweight_il, const void* const* bias, void* const* y, const int* n, int k,
-                       int group_size, int n_out, qeft_stream_t stream) {
+                       const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream) {
     if (nparts < 1 || nparts > 3) return QEFT_ERR_SHAPE;
     if (!x || !qweight || !scales || !scaled_zeros || !y || !n) return QEFT_ERR_NULL;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;
@@ -172,6 +194,8 @@ int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, in
         g.zeros[p] = (const qeft::f16*)scaled_zeros[p];
         g.ow_il[p] = n_out > 0 ? (const qeft::f16*)oweight_il[p] : nullptr;
         g.bias[p] = bias ? (const qeft::f16*)bias[p] : nullptr;
+        g.sz_blk[p] = sz_packed ? (const uint32_t*)sz_packed[p] : nullptr;
+        if (g.sz_blk[p] && !aligned16(g.sz_blk[p])) return QEFT_ERR_ALIGN;
         g.y[p] = (qeft::f16*)y[p];
         g.N[p] = n[p];
     }
@@ -188,8 +212,9 @@ int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, in
 
 int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, const void* scales,
                       const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
-                      void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+                      const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
     if (int e = check_common(n, k, group_size, n_out)) return e;
+    if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (!gate || !up || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
     if (!aligned16(gate) || !aligned16(up) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight_il)))
         return QEFT_ERR_ALIGN;
@@ -211,6 +236,8 @@ int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, con
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
     a.xt_aux = (const qeft::f16*)up;
     a.xt_eps = 0.f;
+    a.sz_blk = (const uint32_t*)sz_packed;
+    a.dbg = nullptr;
     return finish(qeft::gemv_w4_silu_dispatch(a, (hipStream_t)stream));
 }
 
@@ -231,12 +258,12 @@ int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_strea
 }
 
 int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
-                          void* k_cache, void* v_cache, const int* pos, void* out, int n_heads, int n_kv_heads,
-                          int max_seq, qeft_stream_t stream) {
+                          void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out, int n_heads,
+                          int n_kv_heads, int max_seq, qeft_stream_t stream) {
     if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || max_seq < 1 || max_seq > 32768) return QEFT_ERR_SHAPE;
     if (!q || !k || !v || !cos_tab || !sin_tab || !k_cache || !v_cache || !pos || !out) return QEFT_ERR_NULL;
     if (!aligned16(k_cache) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
-    return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache, v_cache, pos, out, n_heads,
+    return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache, v_cache, pos, out_pos, out, n_heads,
                                                 n_kv_heads, max_seq, (hipStream_t)stream));
 }
 

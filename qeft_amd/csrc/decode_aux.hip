@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
                                                                const f16* __restrict__ v, const float* __restrict__ cs,
                                                                const float* __restrict__ sn, f16* __restrict__ kc,
                                                                f16* __restrict__ vc, const int* __restrict__ pos_ptr,
-                                                               f16* __restrict__ out, int n_heads, int n_kv,
-                                                               int max_seq) {
+                                                               const int* __restrict__ out_pos, f16* __restrict__ out,
+                                                               int n_heads, int n_kv, int max_seq) {
     constexpr int HD = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     float* sc = (float*)smem_raw;            // [max_seq] scores / probabilities
@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
         float acc = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc += part[g * HD + t];
-        out[h * HD + t] = (f16)(acc * inv);
+        const int oi = h * HD + t;
+        out[out_pos ? out_pos[oi] : oi] = (f16)(acc * inv);
     }
 }
 
@@ -208,8 +209,8 @@ hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, h
 }
 
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
-                                   void* vc, const int* pos, void* out, int n_heads, int n_kv, int max_seq,
-                                   hipStream_t st) {
+                                   void* vc, const int* pos, const int* out_pos, void* out, int n_heads, int n_kv,
+                                   int max_seq, hipStream_t st) {
     const size_t smem = (size_t)max_seq * 4 + 128 * 4 + 2 * 128 * 2 + 16 * 128 * 4;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)rope_attn_decode_kernel,
@@ -217,8 +218,8 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rope_attn_decode_kernel, dim3(n_heads), dim3(256), smem, st, (const f16*)q, (const f16*)k,
-                       (const f16*)v, (const float*)cs, (const float*)sn, (f16*)kc, (f16*)vc, pos, (f16*)out, n_heads,
-                       n_kv, max_seq);
+                       (const f16*)v, (const float*)cs, (const float*)sn, (f16*)kc, (f16*)vc, pos, out_pos, (f16*)out,
+                       n_heads, n_kv, max_seq);
     return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@
 //  * The fp16 outlier slice replaces the dead nibbles of the last n_out columns: lanes
 //    whose 32-k chunk lies there skip the INT4 load and read 128 B of oweight_interleaved.
 //  * Optional fusions (qeft_gemv_w4_fused): o_proj input gather through LDS, bias, residual.
+#include <cstdlib>
+
 #include "gemv_w4_mfma.h"
 
 namespace qeft {
@@ -70,10 +72,31 @@ static bool mfma_ok(int N, int K, int G, int n_out) {
     return K % 128 == 0 && n_out % 128 == 0 && (G == 128 || G == K) && N % 16 == 0 && N / 16 >= 128;
 }
 
+// Blocks for a layer with `nsets` 16-row sets.  Every block pays ~1 us of start-up plus the x staging before its
+// first MFMA (tools/gemv_lab.hip timeline), so wide layers run as 256*k long-lived blocks that each walk ~3 row sets
+// with the ring never draining; narrow layers (< 2 sets per CU) keep one block per set.  QEFT_GEMV_BLOCKS overrides.
+static int mfma_grid(int nsets) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("QEFT_GEMV_BLOCKS");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced > 0) return nsets < forced ? nsets : forced;
+    if (nsets < 512) return nsets;
+    int k = (nsets + 384) / 768;
+    if (k < 1) k = 1;
+    return 256 * k;
+}
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
 template <int M, int D>
 static hipError_t launch_mfma(const GemvArgs& a, hipStream_t st) {
-    const size_t smem = gemv_mfma_smem_bytes(kNW, M, a.K, a.n_out);
-    const dim3 grid(a.N / 16), block(kNW * 64);
+    const int nsets = a.N / 16;
+    int nblk = (M == 1) ? mfma_grid(nsets) : nsets;
+    int rs_cap = ceil_div(nsets, nblk);
+    if (gemv_mfma_smem_bytes(kNW, M, a.K, a.n_out, rs_cap) > 64 * 1024) { nblk = nsets; rs_cap = 1; }
+    const size_t smem = gemv_mfma_smem_bytes(kNW, M, a.K, a.n_out, rs_cap);
+    const dim3 grid(nblk), block(kNW * 64);
     const bool outl = a.n_out > 0, xg = a.ids != nullptr;
 #define QEFT_LAUNCH(OUTL_, XG_)                                                                                        \
     do {                                                                                                                \
@@ -82,7 +105,7 @@ static hipError_t launch_mfma(const GemvArgs& a, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (e != hipSuccess) return e;                                                                              \
         }                                                                                                               \
-        hipLaunchKernelGGL(kern, grid, block, smem, st, a);                                                             \
+        hipLaunchKernelGGL(kern, grid, block, smem, st, a, rs_cap);                                                     \
     } while (0)
     if (xg) { if (outl) QEFT_LAUNCH(true, true); else QEFT_LAUNCH(false, true); }
     else { if (outl) QEFT_LAUNCH(true, false); else QEFT_LAUNCH(false, false); }
@@ -104,7 +127,7 @@ static hipError_t launch_mfma_m(const GemvArgs& a, int m, hipStream_t st) {
 }
 
 // ring depth (steps in flight per wave), measured with tools/gemv_lab.hip: short rows want 2, long rows 6
-static int mfma_depth(int K) { return K > 6144 ? 6 : 2; }
+static int mfma_depth(int K) { return K > 6144 ? 6 : 4; }
 
 // Row-groups per wave-load: 4 (16 rows per block) when that still gives >= 1 block per CU, fewer for small
 // (e.g. row-sharded) layers so they still cover the 256 CUs.  The staged activations must fit the 160 KB LDS:
@@ -120,7 +143,7 @@ hipError_t gemv_w4_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
                 a.x = a0.x + (size_t)m0 * a0.K;
                 a.y = a0.y + (size_t)m0 * a0.N;
                 if (a0.residual) a.residual = a0.residual + (size_t)m0 * a0.N;
-                const hipError_t e = mfma_depth(a.K) == 6 ? launch_mfma_m<6>(a, mc, st) : launch_mfma_m<2>(a, mc, st);
+                const hipError_t e = mfma_depth(a.K) == 6 ? launch_mfma_m<6>(a, mc, st) : launch_mfma_m<4>(a, mc, st);
                 if (e != hipSuccess) return e;
             }
             return hipSuccess;
@@ -166,15 +189,15 @@ static hipError_t launch_group(const GemvGroupArgs& g, int nblocks, hipStream_t 
 }
 
 template <int D>
-static hipError_t launch_mfma_group(const GemvGroupArgs& g, int nblocks, hipStream_t st) {
-    const size_t smem = gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out);
+static hipError_t launch_mfma_group(const GemvGroupArgs& g, int nblocks, int rs_cap, hipStream_t st) {
+    const size_t smem = gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out, rs_cap);
     const dim3 grid(nblocks), block(kNW * 64);
     if (g.xt_aux) {
-        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 1>), grid, block, smem, st, g);
-        else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 1>), grid, block, smem, st, g);
+        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 1>), grid, block, smem, st, g, rs_cap);
+        else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 1>), grid, block, smem, st, g, rs_cap);
     } else {
-        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 0>), grid, block, smem, st, g);
-        else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 0>), grid, block, smem, st, g);
+        if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 0>), grid, block, smem, st, g, rs_cap);
+        else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 0>), grid, block, smem, st, g, rs_cap);
     }
     return hipGetLastError();
 }
@@ -188,12 +211,30 @@ hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st) {
             ntot += g.N[p];
         }
         if (ok && mfma_ok(ntot, g.K, g.G, g.n_out)) {
-            int acc = 0;
+            // blocks per part proportional to its rows (every part gets >= 1 and <= its row sets)
+            const int nsets = ntot / 16;
+            const int total_blocks = mfma_grid(nsets);
+            int acc = 0, rs_cap = 1;
             for (int p = 0; p < 3; ++p) {
-                if (p < nparts) acc += g.N[p] / 16;
+                if (p < nparts) {
+                    const int sp = g.N[p] / 16;
+                    int bp = (int)((long long)total_blocks * sp / nsets);
+                    if (bp < 1) bp = 1;
+                    if (bp > sp) bp = sp;
+                    acc += bp;
+                    if (ceil_div(sp, bp) > rs_cap) rs_cap = ceil_div(sp, bp);
+                }
                 g.blk_end[p] = acc;
             }
-            return mfma_depth(g.K) == 6 ? launch_mfma_group<6>(g, acc, st) : launch_mfma_group<2>(g, acc, st);
+            if (gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out, rs_cap) > 64 * 1024) {
+                acc = 0;
+                rs_cap = 1;
+                for (int p = 0; p < 3; ++p) {
+                    if (p < nparts) acc += g.N[p] / 16;
+                    g.blk_end[p] = acc;
+                }
+            }
+            return mfma_depth(g.K) == 6 ? launch_mfma_group<6>(g, acc, rs_cap, st) : launch_mfma_group<4>(g, acc, rs_cap, st);
         }
     }
     int total_rgs = 0;
@@ -232,16 +273,19 @@ static hipError_t launch_silu(const GemvArgs& a, hipStream_t st) {
 
 template <int D>
 static hipError_t launch_mfma_silu(const GemvArgs& a, hipStream_t st) {
-    const size_t smem = gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out);
-    const dim3 grid(a.N / 16), block(kNW * 64);
-    if (a.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, true, false, 2, 0>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, false, false, 2, 0>), grid, block, smem, st, a);
+    const int nsets = a.N / 16;
+    int nblk = mfma_grid(nsets), rs_cap = ceil_div(nsets, nblk);
+    if (gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out, rs_cap) > 64 * 1024) { nblk = nsets; rs_cap = 1; }
+    const size_t smem = gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out, rs_cap);
+    const dim3 grid(nblk), block(kNW * 64);
+    if (a.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, true, false, 2, 0>), grid, block, smem, st, a, rs_cap);
+    else hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, false, false, 2, 0>), grid, block, smem, st, a, rs_cap);
     return hipGetLastError();
 }
 
 hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st) {
     if (mfma_ok(a.N, a.K, a.G, a.n_out) && a.K <= 16384 && gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out) <= 64 * 1024)
-        return mfma_depth(a.K) == 6 ? launch_mfma_silu<6>(a, st) : launch_mfma_silu<2>(a, st);
+        return mfma_depth(a.K) == 6 ? launch_mfma_silu<6>(a, st) : launch_mfma_silu<4>(a, st);
     const int rgs = a.N / 4;
     int rgi = 4;
     while (rgi > 1 && (rgs % rgi != 0 || rgs / rgi < 256)) rgi >>= 1;

@@ -388,6 +388,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_group_kernel(GemvGroupArgs g)
     a.gshift = g.gshift;
     a.xt_aux = g.xt_aux;
     a.xt_eps = g.xt_eps;
+    a.sz_blk = nullptr;
+    a.dbg = nullptr;
     gemv_w4_body<NW, RGI, M, D, OUTL, false, 0, XT>(a, blk);
 }
 

@@ -23,39 +23,53 @@
 
 namespace qeft {
 
-__host__ __device__ constexpr size_t gemv_mfma_smem_bytes(int NW, int M, int K, int n_out) {
-    return (size_t)NW * 16 * M * 4 +                                   // red   [NW][M][16] f32
-           (n_out > 0 ? (size_t)16 * gemv_slab_stride(n_out) * 2 : 0) +  // slab  [16][n_out+8] f16 (permuted slots)
-           (size_t)(K / 128) * 16 * 4 +                                 // szl   [K/128][16] (s | sz << 16)
+__host__ __device__ constexpr size_t gemv_mfma_smem_bytes(int NW, int M, int K, int n_out, int RS = 1) {
+    return (size_t)RS * NW * 16 * M * 4 +                              // red   [RS][NW][M][16] f32
+           (n_out > 0 ? (size_t)RS * 16 * gemv_slab_stride(n_out) * 2 : 0) +  // slab  [RS*16][n_out+8] f16 (permuted slots)
+           (size_t)RS * (K / 128) * 16 * 4 +                            // szl   [RS][K/128][16] (s | sz << 16)
            ((size_t)M * (K / 128) * 8 + 15) / 16 * 16 +                 // corr  [M][K/128] (A, B) f32
            (size_t)M * K * 2;                                           // xs    [M][K] f16 (permuted slots, prescaled)
 }
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
+// A block owns RS consecutive 16-row sets (run time).  The block prologue (x staging, optional RMSNorm / SiLU,
+// correction sums) is paid once per block, so wide layers are launched with fewer, longer-lived blocks (a few per
+// CU): one prologue then feeds RS x more weight bytes, and a wave walks its (row set, step) pairs as ONE sequence so
+// the register ring never drains between row sets.
 template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
-__device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int blk) {
+__device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int set0, const int RS, const int rs_cap) {
+    // this block owns the 16-row sets [set0, set0 + RS) of the layer; LDS is carved for rs_cap sets (launch constant)
     static_assert(XT == 0 || (M == 1 && !XG), "x transforms are for the batch-1 decode engine");
     constexpr int kWaves = NW, kBlock = NW * 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    float* red = (float*)smem;
-    f16* slab = (f16*)(smem + NW * 16 * M * 4);
+    float* red = (float*)smem;                                                    // [rs_cap][NW][M][16]
+    f16* slab = (f16*)(smem + rs_cap * NW * 16 * M * 4);                          // [rs_cap*16][n_out + 8]
     const int slab_stride = gemv_slab_stride(a.n_out);
-    uint32_t* szl = (uint32_t*)(slab + (OUTL ? 16 * slab_stride : 0));
+    uint32_t* szl = (uint32_t*)(slab + (OUTL ? rs_cap * 16 * slab_stride : 0));   // [rs_cap][K/128][16]
     const int nsteps = a.K / 128;
-    float* corr = (float*)(szl + nsteps * 16);
+    float* corr = (float*)(szl + rs_cap * nsteps * 16);
     uint32_t* xs32 = (uint32_t*)((uint8_t*)corr + ((size_t)M * nsteps * 8 + 15) / 16 * 16);   // x' as dwords (k-pairs)
     const f16* xs = (const f16*)xs32;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: step bookkeeping stays scalar
     const int nl = lane & 15, kc = lane >> 4;            // row within the block / 32-k chunk within the step
-    const int rg0 = blk * 4;
+    const int rg0 = set0 * 4;
     const int row0 = rg0 * 4;
     const int kq = a.K - (OUTL ? a.n_out : 0);
     const int nfull = kq / 128;                          // INT4 steps; steps [nfull, nsteps) are the fp16 outlier slice
     const int nsw = (nfull - wave + kWaves - 1) / kWaves;
     const bool per_channel = a.gshift == 31;
+    // diagnostic stamps (lab builds only): [block][8] = realtime at entry, shader clock at the phase boundaries
+    unsigned long long stamp[6];
+    auto mark = [&](int i) {
+        if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    };
+    unsigned long long rt0 = 0;
+    if (ABL & 16) rt0 = __builtin_amdgcn_s_memrealtime();
+    mark(0);
 
     // ---- 1. oldest loads: x, the transform operand, the outlier slab, the scales
     const int xtotal = M * a.K;
@@ -72,36 +86,53 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int b
             if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
         }
     }
-    const int slab_vecs = OUTL ? 8 * (2 * a.n_out) / 8 : 0;           // 8 interleaved rows of 2*n_out halves
+    const int slab_vecs = OUTL ? RS * 8 * (2 * a.n_out) / 8 : 0;      // 8 interleaved rows of 2*n_out halves per row set
     const f16* osrc = OUTL ? a.ow_il + (size_t)(rg0 >> 1) * 4 * (2 * a.n_out) : nullptr;
-    u32x4 ost = {0u, 0u, 0u, 0u};
-    if (OUTL) ost = *(const u32x4*)(osrc + (size_t)min(tid, slab_vecs - 1) * 8);
-    const int ngroups = per_channel ? 1 : nsteps;
-    const int szn = ngroups * 8;                                       // dwords of two adjacent rows
-    uint32_t sst[2], zst[2];
+    u32x4 ost[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (OUTL) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int i = min(p * kBlock + tid, szn - 1);
-        const uint32_t so = (uint32_t)(i >> 3) * (uint32_t)a.N + row0 + (i & 7) * 2;
-        sst[p] = (ABL & 1) ? 0x1c001c00u : *(const uint32_t*)(a.scales + so);
-        zst[p] = (ABL & 1) ? 0xa000a000u : *(const uint32_t*)(a.zeros + so);
+        for (int p = 0; p < 2; ++p) ost[p] = *(const u32x4*)(osrc + (size_t)min(p * kBlock + tid, slab_vecs - 1) * 8);
+    }
+    const int ngroups = per_channel ? 1 : nsteps;
+    const int szn = ngroups * 8 * RS;                                  // dword pairs of two adjacent rows
+    uint32_t sst[2], zst[2];
+    u32x4 szv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    const int szvecs = RS * ngroups * 4;                               // 16-byte pieces of the block's shadow scales
+    const uint32_t* szsrc = a.sz_blk ? a.sz_blk + (size_t)set0 * ngroups * 16 : nullptr;
+    if (a.sz_blk) {
+        // contiguous [RS][K/G][16] dwords for this block: coalesced 16-byte loads
+#pragma unroll
+        for (int p = 0; p < 2; ++p) szv[p] = *(const u32x4*)(szsrc + (size_t)min(p * kBlock + tid, szvecs - 1) * 4);
+    } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = min(p * kBlock + tid, szn - 1);
+            const uint32_t so = (uint32_t)(i / (8 * RS)) * (uint32_t)a.N + row0 + (i % (8 * RS)) * 2;
+            sst[p] = (ABL & 1) ? 0x1c001c00u : *(const uint32_t*)(a.scales + so);
+            zst[p] = (ABL & 1) ? 0xa000a000u : *(const uint32_t*)(a.zeros + so);
+        }
     }
 
     // ---- 2. weight stream: ring of D steps per wave (steps wave, wave+NW, ...), branch-free, oldest first
-    const int s_last = max(wave + (nsw - 1) * kWaves, 0);
+    // The wave's work is the sequence t = 0 .. RS*nsw-1 of (row set rs = t / nsw, step s = wave + NW * (t % nsw)).
     u32x4 ring[D];
     const uint8_t* wbase = a.qw + (size_t)(rg0 + (nl >> 2)) * a.K * 2 + (kc >> 1) * 128 + (nl & 3) * 32 + (kc & 1) * 16;
-    auto issue = [&](u32x4& b, int s) {
-        s = min(s, s_last);
-        const uint32_t woff = min((uint32_t)s * 256u, (uint32_t)a.K * 2 - 256u);   // stays inside the row-group
-        b = __builtin_nontemporal_load((const u32x4*)(wbase + woff));
+    const uint32_t rs_bytes = (uint32_t)a.K * 8u;                      // 4 row-groups of 2K bytes per row set
+    int p_rs = 0, p_i = 0;                                             // (row set, index) of the next step to issue
+    auto issue = [&](u32x4& b) {
+        // past the end (or a wave without ring steps): harmless re-read of a valid address inside the row-group
+        const int irs = min(p_rs, RS - 1);
+        const uint32_t woff = min((uint32_t)(wave + p_i * kWaves) * 256u, (uint32_t)a.K * 2 - 256u);
+        b = __builtin_nontemporal_load((const u32x4*)(wbase + (size_t)irs * rs_bytes + woff));
+        if (++p_i >= nsw) { p_i = 0; ++p_rs; }
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        issue(ring[d], wave + d * kWaves);
+        issue(ring[d]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    mark(1);
     // ---- 2b. optional x transform on the register-held vectors
     if (XT == 1) {
         float ss = 0.f;
@@ -142,15 +173,25 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int b
     }
 
     // ---- 3. stage scales, x' (+ per-step sums) and the outlier slab into LDS
+    if (a.sz_blk) {
+        for (int v = tid; v < szvecs; v += kBlock) {
+            const u32x4 t = (v == tid) ? szv[0] : (v == tid + kBlock) ? szv[1] : *(const u32x4*)(szsrc + (size_t)v * 4);
+            const int rs = v / (ngroups * 4), rem = v % (ngroups * 4);     // shadow is [rs][group][16]; LDS is [rs][nsteps][16]
+            *(u32x4*)(szl + (rs * nsteps + (rem >> 2)) * 16 + (rem & 3) * 4) = t;
+        }
+    } else
     for (int i = tid, p = 0; i < szn; i += kBlock, ++p) {
         uint32_t sv = sst[0], zv = zst[0];
         if (p == 1) { sv = sst[1]; zv = zst[1]; }
+        const int grp = i / (8 * RS), pr = i % (8 * RS);
         if (p >= 2) {
-            const uint32_t so = (uint32_t)(i >> 3) * (uint32_t)a.N + row0 + (i & 7) * 2;
+            const uint32_t so = (uint32_t)grp * (uint32_t)a.N + row0 + pr * 2;
             sv = *(const uint32_t*)(a.scales + so);
             zv = *(const uint32_t*)(a.zeros + so);
         }
-        *(u32x2*)(szl + i * 2) = u32x2{__builtin_amdgcn_perm(zv, sv, 0x05040100u), __builtin_amdgcn_perm(zv, sv, 0x07060302u)};
+        // row set pr/8, rows (pr%8)*2, +1 of it
+        *(u32x2*)(szl + ((pr >> 3) * nsteps + grp) * 16 + (pr & 7) * 2) =
+            u32x2{__builtin_amdgcn_perm(zv, sv, 0x05040100u), __builtin_amdgcn_perm(zv, sv, 0x07060302u)};
     }
     {
         const h2 k16th = {(f16)0.0625f, (f16)0.0625f};
@@ -207,7 +248,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int b
         uint32_t* slab32 = (uint32_t*)slab;
         const int sstr = slab_stride / 2;   // dwords per slab row
         for (int v = tid; v < slab_vecs; v += kBlock) {
-            const u32x4 ov = (v == tid) ? ost : *(const u32x4*)(osrc + (size_t)v * 8);
+            const u32x4 ov = (v == tid) ? ost[0] : (v == tid + kBlock) ? ost[1] : *(const u32x4*)(osrc + (size_t)v * 8);
             const int per_row = (2 * a.n_out) / 8;
             const int ir = v / per_row, piece = v % per_row;
             const int c32 = piece >> 3, d0 = (piece & 7) * 2;          // natural dwords d0, d0+1 of the chunk
@@ -224,105 +265,171 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int b
         }
     }
     __syncthreads();
+    mark(2);
 
     // ---- 4. steps
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};     // acc[j]: batch row m = 4*kc + j, weight row nl
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};     // acc[j]: batch row m = 4*kc + j, weight row nl of the current row set
     uint32_t MAGIC = 0x64006400u;
     asm volatile("" : "+v"(MAGIC));
     const int am = min(nl, M - 1);         // A-operand row of this lane (rows >= M replicate row M-1, never stored)
     const f16* xa = xs + (size_t)am * a.K + kc * 32;
 
-    auto consume = [&](const u32x4& wv, int s) {
-        if (ABL & 4) {
-            acc[0] += __builtin_bit_cast(float, wv[0] ^ wv[1] ^ wv[2] ^ wv[3]);
-            return;
-        }
-        f32x4 P0 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};   // two chains: MFMA latency is exposed at 2 waves/SIMD
-        const h8v* px = (const h8v*)(xa + (size_t)s * 128);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t v = wv[w], t = v >> 8;
-            const u32x4 bw = {(v & 0x000f000fu) | MAGIC, (v & 0x00f000f0u) | MAGIC, (t & 0x000f000fu) | MAGIC,
-                              (t & 0x00f000f0u) | MAGIC};
-            if (w & 1) P1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], __builtin_bit_cast(h8v, bw), P1, 0, 0, 0);
-            else P0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], __builtin_bit_cast(h8v, bw), P0, 0, 0, 0);
-        }
-        const h2 szp = as_h2(szl[(per_channel ? 0 : s) * 16 + nl]);
-        const float sf = (float)szp[0], zf = (float)szp[1];
-#pragma unroll
-        for (int j = 0; j < (M < 4 ? M : 4); ++j) {       // batch row m = 4*kc + j; rows >= M are never stored
-            const int m = min(4 * kc + j, M - 1);
-            const float2 ab = *(const float2*)(corr + ((size_t)m * nsteps + s) * 2);
-            acc[j] += sf * ((P0[j] + P1[j]) - ab.x) + zf * ab.y;
-        }
-    };
-
-    // fp16 outlier steps [nfull, nsteps): B fragments straight from the LDS slab (same slot order), no correction
-    if (OUTL) {
+    // fp16 outlier steps [nfull, nsteps) of row set rs: B fragments straight from the LDS slab (same slot order)
+    auto outlier_steps = [&](int rs) {
+        if (!OUTL) return;
         for (int s = nfull + ((wave - nfull) % kWaves + kWaves) % kWaves; s < nsteps; s += kWaves) {
             const h8v* px = (const h8v*)(xa + (size_t)s * 128);
-            const h8v* pw = (const h8v*)(slab + (size_t)nl * slab_stride + (s - nfull) * 128 + kc * 32);
+            const h8v* pw = (const h8v*)(slab + (size_t)(rs * 16 + nl) * slab_stride + (s - nfull) * 128 + kc * 32);
             f32x4 P = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) P = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], pw[w], P, 0, 0, 0);
             if (!(ABL & 4)) acc += P;
         }
-    }
+    };
+    auto flush = [&](int rs) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = 4 * kc + j;
+            if (m < M) red[((rs * kWaves + wave) * M + m) * 16 + nl] = acc[j];
+        }
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 
-    const int nrounds = max((nsw + D - 1) / D, 1);
-    for (int rd = 0; rd + 1 < nrounds; ++rd) {
+    // LDS operands of a step (A fragments, the row's scale word, the step's correction sums) are fetched one step
+    // ahead into two alternating register sets, so no step waits for LDS after its weights arrived.
+    struct StepOps {
+        h8v x[4];
+        uint32_t szw;
+        float2 ab[M < 4 ? M : 4];
+    };
+    int c_rs = 0, c_i = 0;                 // (row set, index) of the next step to consume
+    auto fetch_ops = [&](StepOps& o) {
+        const int rs = min(c_rs, RS - 1);  // past the end: harmless in-range read
+        const int s = wave + c_i * kWaves;
+        const h8v* px = (const h8v*)(xa + (size_t)s * 128);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o.x[w] = px[w];
+        o.szw = szl[(rs * nsteps + (per_channel ? 0 : s)) * 16 + nl];
+#pragma unroll
+        for (int j = 0; j < (M < 4 ? M : 4); ++j) {       // batch row m = 4*kc + j; rows >= M are never stored
+            const int m = min(4 * kc + j, M - 1);
+            o.ab[j] = *(const float2*)(corr + ((size_t)m * nsteps + s) * 2);
+        }
+    };
+    auto consume = [&](const u32x4& wv, const StepOps& cur, StepOps& nxt) {
+        if (c_i == 0) outlier_steps(c_rs);
+        const int rs_now = c_rs;
+        const bool last_of_set = c_i + 1 >= nsw;
+        if (last_of_set) { c_i = 0; ++c_rs; } else { ++c_i; }
+        fetch_ops(nxt);                                   // LDS reads for the NEXT step go out before this one's math
+        if (ABL & 4) {
+            acc[0] += __builtin_bit_cast(float, wv[0] ^ wv[1] ^ wv[2] ^ wv[3]);
+        } else {
+            f32x4 P0 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};   // two chains: MFMA latency is exposed at 2 waves/SIMD
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t v = wv[w], t = v >> 8;
+                const u32x4 bw = {(v & 0x000f000fu) | MAGIC, (v & 0x00f000f0u) | MAGIC, (t & 0x000f000fu) | MAGIC,
+                                  (t & 0x00f000f0u) | MAGIC};
+                if (w & 1) P1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[w], __builtin_bit_cast(h8v, bw), P1, 0, 0, 0);
+                else P0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[w], __builtin_bit_cast(h8v, bw), P0, 0, 0, 0);
+            }
+            const h2 szp = as_h2(cur.szw);
+            const float sf = (float)szp[0], zf = (float)szp[1];
+#pragma unroll
+            for (int j = 0; j < (M < 4 ? M : 4); ++j) acc[j] += sf * ((P0[j] + P1[j]) - cur.ab[j].x) + zf * cur.ab[j].y;
+        }
+        if (last_of_set) flush(rs_now);
+    };
+
+    if (nsw == 0) {
+        // K has no full INT4 step for this wave: only (possibly) outlier steps
+        for (int rs = 0; rs < RS; ++rs) {
+            outlier_steps(rs);
+            flush(rs);
+        }
+    } else {
+        static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
+        const int total = RS * nsw;
+        const int nrounds = (total + D - 1) / D;
+        StepOps opA, opB;
+        fetch_ops(opA);
+        for (int rd = 0; rd + 1 < nrounds; ++rd) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (d & 1) consume(ring[d], opB, opA);
+                else consume(ring[d], opA, opB);
+                issue(ring[d]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int si = rd * D + d;
-            consume(ring[d], wave + si * kWaves);
-            issue(ring[d], wave + (si + D) * kWaves);
+            if ((nrounds - 1) * D + d < total) {
+                if (d & 1) consume(ring[d], opB, opA);
+                else consume(ring[d], opA, opB);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int si = (nrounds - 1) * D + d;
-        if (si < nsw) consume(ring[d], wave + si * kWaves);
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
+    mark(3);
     // ---- 5. combine the waves
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = 4 * kc + j;
-        if (m < M) red[(wave * M + m) * 16 + nl] = acc[j];
-    }
     __syncthreads();
-    if (tid < 16 * M) {
-        const int m = tid >> 4, n = tid & 15;
+    mark(4);
+    for (int o = tid; o < RS * 16 * M; o += kBlock) {
+        const int rs = o / (16 * M), m = (o / 16) % M, n = o & 15;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) v += red[(w * M + m) * 16 + n];
-        const int orow = row0 + n;
+        for (int w = 0; w < kWaves; ++w) v += red[((rs * kWaves + w) * M + m) * 16 + n];
+        const int orow = row0 + rs * 16 + n;
         if (a.bias) v += (float)a.bias[orow];
         if (a.residual) v += (float)a.residual[(size_t)m * a.N + orow];
         a.y[(size_t)m * a.N + orow] = (f16)v;
     }
+    if ((ABL & 16) && a.dbg && (tid & 63) == 0) {
+        mark(5);
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * kWaves + wave) * 8;
+        d[0] = rt0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[2 + i] = stamp[i];
+    }
 }
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Neighbouring row blocks share the 128-byte
-// lines of scales / scaled_zeros (4 blocks per line) and of oweight_interleaved, so give each XCD a contiguous range
-// of row blocks: the lines are then fetched into one L2 instead of four.  Speed only; any placement is correct.
+// lines of scales / scaled_zeros and of oweight_interleaved, so give each XCD a contiguous range of row blocks.
+// Speed only; any placement is correct.
 __device__ __forceinline__ int xcd_contiguous_block(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
-__global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_kernel(GemvArgs a) {
-    gemv_w4_mfma_body<NW, M, D, OUTL, XG, XT, ABL>(a, (ABL & 8) ? (int)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x));
+// Row sets [0, nsets) dealt to nblk blocks as evenly as possible: the first (nsets % nblk) blocks get one more.
+__device__ __forceinline__ void block_sets(int b, int nblk, int nsets, int& set0, int& cnt) {
+    const int q = nsets / nblk, r = nsets % nblk;
+    set0 = b * q + min(b, r);
+    cnt = q + (b < r ? 1 : 0);
 }
 
+template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_kernel(GemvArgs a, int rs_cap) {
+    const int b = (ABL & 8) ? (int)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int set0, cnt;
+    block_sets(b, gridDim.x, a.N / 16, set0, cnt);
+    gemv_w4_mfma_body<NW, M, D, OUTL, XG, XT, ABL>(a, set0, cnt, rs_cap);
+}
+
+// Several linears that share the same input (q/k/v, gate/up) in ONE launch, batch 1: blocks [blk_end[p-1], blk_end[p])
+// work on part p and split its row sets evenly.
 template <int NW, int D, bool OUTL, int XT = 0>
-__global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupArgs g) {
+__global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupArgs g, int rs_cap) {
     const int gb = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    int p = 0, blk = gb;
-    if (gb >= g.blk_end[0]) { p = 1; blk = gb - g.blk_end[0]; if (gb >= g.blk_end[1]) { p = 2; blk = gb - g.blk_end[1]; } }
+    int p = 0, blk = gb, nb = g.blk_end[0];
+    if (gb >= g.blk_end[0]) {
+        p = 1; blk = gb - g.blk_end[0]; nb = g.blk_end[1] - g.blk_end[0];
+        if (gb >= g.blk_end[1]) { p = 2; blk = gb - g.blk_end[1]; nb = g.blk_end[2] - g.blk_end[1]; }
+    }
     GemvArgs a;
     a.x = g.x;
     a.qw = g.qw[p];
@@ -340,7 +447,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupAr
     a.gshift = g.gshift;
     a.xt_aux = g.xt_aux;
     a.xt_eps = g.xt_eps;
-    gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0>(a, blk);
+    a.sz_blk = g.sz_blk[p];
+    a.dbg = nullptr;
+    int set0, cnt;
+    block_sets(blk, nb, a.N / 16, set0, cnt);
+    gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0>(a, set0, cnt, rs_cap);
 }
 
 }  // namespace qeft

@@ -62,6 +62,8 @@ struct GemvArgs {
     int gshift;  // log2(G) for power-of-two groups, 31 when G == K (single group)
     const f16* xt_aux;   // x transform operand (gamma or up), see gemv_w4_kernel.h XT
     float xt_eps;
+    const uint32_t* sz_blk;  // optional shadow [N/16][K/G][16] of (scale | scaled_zero << 16), see qeft_pack_scales
+    unsigned long long* dbg; // tools/gemv_lab.hip only (ABL & 16): per-block time stamps; always NULL in the product
 };
 
 struct GemvGroupArgs {
@@ -77,6 +79,7 @@ struct GemvGroupArgs {
     int K, G, n_out, gshift;
     const f16* xt_aux;
     float xt_eps;
+    const uint32_t* sz_blk[3];
 };
 
 __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }

@@ -245,12 +245,20 @@ class DecodeEngine:
         # per-layer local linears + argument packs (host arrays of device pointers must stay alive)
         self.lin = []
         self.packs = []
+        self.att_pos = []   # per layer: where attention output element i goes so that o_proj needs no gather
         for L in model.model.layers:
             a, mlp = L.self_attn, L.mlp
             names = dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.o_proj, g=mlp.gate_proj, u=mlp.up_proj, d=mlp.down_proj)
             if P > 1:
                 names = {kk: shard_quantlinear(vv, self.rank, P).to(dev) for kk, vv in names.items()}
             self.lin.append(names)
+            o = names["o"]
+            if hasattr(o, "reorder_ids"):
+                inv = torch.empty_like(o.reorder_ids)
+                inv[o.reorder_ids] = torch.arange(o.reorder_ids.numel(), device=inv.device)
+                self.att_pos.append(inv.to(torch.int32).to(dev))
+            else:
+                self.att_pos.append(None)
             qkv = [names["q"], names["k"], names["v"]]
             gu = [names["g"], names["u"]]
             no = s.n_out
@@ -262,11 +270,13 @@ class DecodeEngine:
                 qkv=(_ptr_array([l.qweight for l in qkv]), _ptr_array([l.scales for l in qkv]),
                      _ptr_array([l.scaled_zeros for l in qkv]),
                      _ptr_array([l.oweight_interleaved for l in qkv]) if no else None,
-                     _ptr_array(qkv_y), (ctypes.c_int * 3)(self.hs, self.kvs, self.kvs)),
+                     _ptr_array(qkv_y), (ctypes.c_int * 3)(self.hs, self.kvs, self.kvs),
+                     _ptr_array([l._szp(l.scales) for l in qkv])),
                 gu=(_ptr_array([l.qweight for l in gu]), _ptr_array([l.scales for l in gu]),
                     _ptr_array([l.scaled_zeros for l in gu]),
                     _ptr_array([l.oweight_interleaved for l in gu]) if no else None,
-                    _ptr_array([self.gate_loc, self.up_loc]), (ctypes.c_int * 2)(self.its, self.its)),
+                    _ptr_array([self.gate_loc, self.up_loc]), (ctypes.c_int * 2)(self.its, self.its),
+                    _ptr_array([l._szp(l.scales) for l in gu])),
             ))
 
     @property
@@ -299,9 +309,9 @@ class DecodeEngine:
         for li, L in enumerate(self.m.model.layers):
             lin, pk = self.lin[li], self.packs[li]
             # input_layernorm is fused into the q|k|v launch (x is normalised while it is staged)
-            qw, sc, sz, ow, ys, ns = pk["qkv"]
+            qw, sc, sz, ow, ys, ns, szp = pk["qkv"]
             ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None,
-                                      ys, ns, s.hidden, g, no, st))
+                                      szp, ys, ns, s.hidden, g, no, st))
             if P > 1:
                 dist.all_gather_into_tensor(self.qkv_all.view(-1), self.qkv_loc, group=self.tp_group)
                 self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
@@ -311,23 +321,26 @@ class DecodeEngine:
                 ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
                                              self.m.rope_cos.data_ptr(), self.m.rope_sin.data_ptr(),
                                              self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                             self.att_pos[li].data_ptr() if self.att_pos[li] is not None else None,
                                              self.att.data_ptr(), s.n_heads, s.n_kv_heads, s.max_seq, st))
             o = lin["o"]
-            ids = o.reorder_ids32.data_ptr() if hasattr(o, "reorder_ids32") else None
+            ids = None   # the attention kernel already stored its output in o_proj's column order
             ow_o = o.oweight_interleaved.data_ptr() if no else None
+            szp_o = o._szp(o.scales)
+            szp_o = szp_o.data_ptr() if szp_o is not None else None
             if P > 1:
                 ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
-                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h[r0:r0 + self.hs].data_ptr(),
+                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h[r0:r0 + self.hs].data_ptr(), szp_o,
                                           self.h_loc.data_ptr(), 1, self.hs, s.hidden, g, no, st))
                 dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
                 h, h2 = h2, h
             else:
                 ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
-                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h.data_ptr(), h.data_ptr(), 1,
-                                          s.hidden, s.hidden, g, no, st))
-            qw, sc, sz, ow, ys, ns = pk["gu"]
+                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h.data_ptr(), szp_o, h.data_ptr(),
+                                          1, s.hidden, s.hidden, g, no, st))
+            qw, sc, sz, ow, ys, ns, szp = pk["gu"]
             ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz,
-                                      ow, None, ys, ns, s.hidden, g, no, st))
+                                      ow, None, szp, ys, ns, s.hidden, g, no, st))
             if P > 1:
                 if not linears_only:
                     ck(lib.qeft_silu_mul(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), self.act_loc.data_ptr(),
@@ -335,17 +348,19 @@ class DecodeEngine:
                 dist.all_gather_into_tensor(self.act, self.act_loc, group=self.tp_group)
             d = lin["d"]
             ow_d = d.oweight_interleaved.data_ptr() if no else None
+            szp_d = d._szp(d.scales)
+            szp_d = szp_d.data_ptr() if szp_d is not None else None
             if P > 1:
                 ck(lib.qeft_gemv_w4_fused(self.act.data_ptr(), d.qweight.data_ptr(), d.scales.data_ptr(),
                                           d.scaled_zeros.data_ptr(), ow_d, None, None, h[r0:r0 + self.hs].data_ptr(),
-                                          self.h_loc.data_ptr(), 1, self.hs, s.inter, g, no, st))
+                                          szp_d, self.h_loc.data_ptr(), 1, self.hs, s.inter, g, no, st))
                 dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
                 h, h2 = h2, h
             else:
                 # silu(gate) * up is formed while down_proj stages its input
                 ck(lib.qeft_gemv_w4_silu(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), d.qweight.data_ptr(),
                                          d.scales.data_ptr(), d.scaled_zeros.data_ptr(), ow_d, None, h.data_ptr(),
-                                         h.data_ptr(), s.hidden, s.inter, g, no, st))
+                                         szp_d, h.data_ptr(), s.hidden, s.inter, g, no, st))
         if linears_only:
             return
         # an even number of buffer swaps per token: the result is back in hbuf[0]

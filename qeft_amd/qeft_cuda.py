@@ -97,8 +97,9 @@ def gemm_4bit_qeft(in_feats, kernel, scales, zeros, oweights, bias=None):
 # ---- entry points beyond the reference's module (used by QuantLinear's fused paths and the backward) ----
 
 def gemv_4bit_fused(in_feats, kernel, scaling_factors, zeros, oweight_il, bias, reorder_ids, residual, m, n, k,
-                    group_size):
-    """One launch for everything QuantLinear.forward_* does around the GEMV (qlinear.py:244-330)."""
+                    group_size, sz_packed=None):
+    """One launch for everything QuantLinear.forward_* does around the GEMV (qlinear.py:244-330).
+    sz_packed: optional derived buffer from pack_scales() (block-contiguous scales for the MFMA GEMV)."""
     _check_common(in_feats, kernel, scaling_factors, zeros)
     x = in_feats.contiguous()
     _need(x.numel() == m * k, f"in_feats has {x.numel()} elements, expected m*k = {m * k}")
@@ -115,8 +116,21 @@ def gemv_4bit_fused(in_feats, kernel, scaling_factors, zeros, oweight_il, bias, 
             x.data_ptr(), kernel.data_ptr(), scaling_factors.data_ptr(), zeros.data_ptr(),
             oweight_il.data_ptr() if n_out else None, bias.data_ptr() if bias is not None else None,
             reorder_ids.data_ptr() if reorder_ids is not None else None,
-            residual.data_ptr() if residual is not None else None, out.data_ptr(), m, n, k, group_size, n_out,
+            residual.data_ptr() if residual is not None else None,
+            sz_packed.data_ptr() if sz_packed is not None else None, out.data_ptr(), m, n, k, group_size, n_out,
             _stream(x)))
+    return out
+
+
+def pack_scales(scales, zeros, n, k, group_size):
+    """Derived buffer int32 [N/16, K/g, 16] = scale | scaled_zero << 16 (qeft_pack_scales).  None when the layer
+    does not qualify (group size other than 128 / per-channel, N % 16 != 0, not on a GPU)."""
+    if not scales.is_cuda or n % 16 != 0 or group_size not in (128, k):
+        return None
+    out = torch.empty(n // 16, k // group_size, 16, dtype=torch.int32, device=scales.device)
+    with torch.cuda.device(scales.device):
+        _lib.check(_lib.lib().qeft_pack_scales(scales.data_ptr(), zeros.data_ptr(), out.data_ptr(), n, k, group_size,
+                                               _stream(scales)))
     return out
 
 

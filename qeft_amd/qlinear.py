@@ -183,6 +183,9 @@ class QuantLinear(nn.Module):
     # ------------------------------------------------------------------ set_kernel (qlinear.py:217-237)
     def set_kernel(self, training=False):
         self.training = training
+        # derived, never saved: block-contiguous (scale | scaled_zero) words for the decode GEMV
+        self.sz_packed = qeft_cuda.pack_scales(self.scales, self.scaled_zeros, self.outfeatures, self.infeatures,
+                                               self.group_size)
         if self.outlierfeatures > 0:
             if self.oweight.shape[1] % 64 > 0:  # same left-padding as the reference (:221-222)
                 pad = 64 - self.oweight.shape[1] % 64
@@ -219,6 +222,14 @@ class QuantLinear(nn.Module):
             else:
                 self.oweight_interleaved = pack_oweight(ow)
 
+    def _szp(self, x):
+        """The derived scale buffer, (re)built lazily if the module moved to another device after set_kernel()."""
+        szp = getattr(self, "sz_packed", None)
+        if szp is None or szp.device != x.device or self.scales.device != x.device:
+            szp = self.sz_packed = qeft_cuda.pack_scales(self.scales, self.scaled_zeros, self.outfeatures,
+                                                         self.infeatures, self.group_size)
+        return szp
+
     # ------------------------------------------------------------------ forwards (qlinear.py:244-330)
     def _outlier_weight_f16(self):
         ow = self.oweight
@@ -235,7 +246,7 @@ class QuantLinear(nn.Module):
             if seq_len < 8:
                 return qeft_cuda.gemv_4bit_fused(x, self.qweight, self.scales, self.scaled_zeros,
                                                  self.oweight_interleaved, self.bias, None, None, seq_len,
-                                                 self.outfeatures, self.infeatures, self.group_size)
+                                                 self.outfeatures, self.infeatures, self.group_size, self._szp(x))
             return qeft_cuda.gemm_4bit_qeft(x, self.qweight, self.scales, self.scaled_zeros,
                                             self._outlier_weight_f16(), self.bias)
         if seq_len < 8:
@@ -256,7 +267,7 @@ class QuantLinear(nn.Module):
             # gather folded into the GEMV's x staging
             return qeft_cuda.gemv_4bit_fused(x, self.qweight, self.scales, self.scaled_zeros,
                                              self.oweight_interleaved, self.bias, self.reorder_ids32, None, seq_len,
-                                             self.outfeatures, self.infeatures, self.group_size)
+                                             self.outfeatures, self.infeatures, self.group_size, self._szp(x))
         inputs = torch.index_select(x, -1, self.reorder_ids)
         if self.fused:
             return qeft_cuda.gemm_4bit_qeft(inputs, self.qweight, self.scales, self.scaled_zeros,
@@ -278,7 +289,7 @@ class QuantLinear(nn.Module):
             if seq_len < 8:
                 return qeft_cuda.gemv_4bit_fused(x, self.qweight, self.scales, self.scaled_zeros, None, self.bias,
                                                  None, None, seq_len, self.outfeatures, self.infeatures,
-                                                 self.group_size)
+                                                 self.group_size, self._szp(x))
             return qeft_cuda.gemm_4bit_qeft(x, self.qweight, self.scales, self.scaled_zeros, None, self.bias)
         if seq_len < 8:
             y = self.gemv(x, self.qweight, self.scales, self.scaled_zeros, seq_len, self.outfeatures,

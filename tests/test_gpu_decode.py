@@ -74,7 +74,7 @@ def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps):
         pos.fill_(t)
         _lib.check(_lib.lib().qeft_rope_attn_decode(Q[t].data_ptr(), K[t].data_ptr(), V[t].data_ptr(), cs.data_ptr(),
                                                     sn.data_ptr(), kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
-                                                    out.data_ptr(), n_heads, n_kv, max_seq, _st()))
+                                                    None, out.data_ptr(), n_heads, n_kv, max_seq, _st()))
         if t in (0, 1, steps // 2, steps - 1):
             q = rope(Q[t], t)                                                  # [H, 128]
             rep = n_heads // n_kv
@@ -85,6 +85,15 @@ def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps):
             torch.cuda.synchronize()
             assert torch.allclose(out.float(), ref, rtol=5e-3, atol=5e-3), t
     assert torch.allclose(kc[:, :steps].float().transpose(0, 1), kr, atol=1e-3)
+    # out_pos: the same output, scattered (used to pre-apply o_proj's column order)
+    perm = torch.randperm(n_heads * hd, device=DEV).to(torch.int32)
+    out2 = torch.empty_like(out)
+    pos.fill_(steps - 1)
+    _lib.check(_lib.lib().qeft_rope_attn_decode(Q[-1].data_ptr(), K[-1].data_ptr(), V[-1].data_ptr(), cs.data_ptr(),
+                                                sn.data_ptr(), kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
+                                                perm.data_ptr(), out2.data_ptr(), n_heads, n_kv, max_seq, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(out2[perm.long()], out)
 
 
 @pytest.mark.parametrize("ns,k,r", [((4096, 4096, 4096), 4096, 128), ((11008, 11008), 4096, 128), ((256, 64, 64), 512, 0),
@@ -104,7 +113,7 @@ def test_grouped_gemv_equals_separate_launches(ns, k, r):
         return a
     _lib.check(_lib.lib().qeft_gemv_w4_group(
         x.data_ptr(), None, 0.0, len(ns), arr([l["qweight"] for l in layers]), arr([l["scales"] for l in layers]),
-        arr([l["scaled_zeros"] for l in layers]), arr([l["oweight_interleaved"] for l in layers]) if r else None, None,
+        arr([l["scaled_zeros"] for l in layers]), arr([l["oweight_interleaved"] for l in layers]) if r else None, None, None,
         arr(ys), (ctypes.c_int * len(ns))(*ns), k, g, r, _st()))
     for l, n, y in zip(layers, ns, ys):
         if r:
@@ -174,9 +183,12 @@ def test_fused_rmsnorm_group_equals_unfused(ns, k):
              _arr([l["scaled_zeros"] for l in layers]), _arr([l["oweight_interleaved"] for l in layers]))
     nn_ = (ctypes.c_int * len(ns))(*ns)
     _lib.check(lib.qeft_rmsnorm(x.data_ptr(), None, gamma.data_ptr(), None, xn.data_ptr(), 1, k, 1e-5, _st()))
-    _lib.check(lib.qeft_gemv_w4_group(xn.data_ptr(), None, 0.0, len(ns), *packs, None, _arr(y0), nn_, k, g, r, _st()))
-    _lib.check(lib.qeft_gemv_w4_group(x.data_ptr(), gamma.data_ptr(), 1e-5, len(ns), *packs, None, _arr(y1), nn_, k, g,
-                                      r, _st()))
+    _lib.check(lib.qeft_gemv_w4_group(xn.data_ptr(), None, 0.0, len(ns), *packs, None, None, _arr(y0), nn_, k, g, r,
+                                      _st()))
+    from qeft_amd import qeft_cuda
+    szp = [qeft_cuda.pack_scales(l["scales"], l["scaled_zeros"], n, k, g) for l, n in zip(layers, ns)]
+    _lib.check(lib.qeft_gemv_w4_group(x.data_ptr(), gamma.data_ptr(), 1e-5, len(ns), *packs, None, _arr(szp), _arr(y1),
+                                      nn_, k, g, r, _st()))
     torch.cuda.synchronize()
     for a, b in zip(y0, y1):
         assert torch.equal(a, b)
@@ -197,9 +209,33 @@ def test_fused_silu_down_equals_unfused(n, k):
     _lib.check(lib.qeft_silu_mul(gate.data_ptr(), up.data_ptr(), act.data_ptr(), k, _st()))
     _lib.check(lib.qeft_gemv_w4_fused(act.data_ptr(), l["qweight"].data_ptr(), l["scales"].data_ptr(),
                                       l["scaled_zeros"].data_ptr(), l["oweight_interleaved"].data_ptr(), None, None,
-                                      res.data_ptr(), y0.data_ptr(), 1, n, k, g, r, _st()))
+                                      res.data_ptr(), None, y0.data_ptr(), 1, n, k, g, r, _st()))
+    from qeft_amd import qeft_cuda
+    szp = qeft_cuda.pack_scales(l["scales"], l["scaled_zeros"], n, k, g)
     _lib.check(lib.qeft_gemv_w4_silu(gate.data_ptr(), up.data_ptr(), l["qweight"].data_ptr(), l["scales"].data_ptr(),
                                      l["scaled_zeros"].data_ptr(), l["oweight_interleaved"].data_ptr(), None,
-                                     res.data_ptr(), y1.data_ptr(), n, k, g, r, _st()))
+                                     res.data_ptr(), szp.data_ptr(), y1.data_ptr(), n, k, g, r, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("n,k,g", [(4096, 4096, 128), (256, 512, 128), (64, 2048, 2048)])
+def test_pack_scales_shadow_layout_and_equivalence(n, k, g):
+    """qeft_pack_scales: out[n/16][grp][n%16] = scale | scaled_zero << 16, and the GEMV gives identical results
+    with and without the shadow."""
+    from qeft_amd import qeft_cuda
+    l = layer_to_torch(O.make_layer(n, k, 128, g, seed=41), DEV)
+    szp = qeft_cuda.pack_scales(l["scales"], l["scaled_zeros"], n, k, g)
+    s16 = l["scales"].view(torch.int16).to(torch.int32) & 0xFFFF
+    z16 = l["scaled_zeros"].view(torch.int16).to(torch.int32) & 0xFFFF
+    word = (s16 | (z16 << 16)).to(torch.int32)                     # [groups, N]
+    ref = word.reshape(k // g, n // 16, 16).permute(1, 0, 2).contiguous()
+    torch.cuda.synchronize()
+    assert torch.equal(szp, ref)
+    x = torch.from_numpy(O.make_activation(2, k, 128, seed=2)).to(DEV)
+    y0 = qeft_cuda.gemv_4bit_fused(x, l["qweight"], l["scales"], l["scaled_zeros"], l["oweight_interleaved"], None, None,
+                                   None, 2, n, k, g)
+    y1 = qeft_cuda.gemv_4bit_fused(x, l["qweight"], l["scales"], l["scaled_zeros"], l["oweight_interleaved"], None, None,
+                                   None, 2, n, k, g, szp)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)

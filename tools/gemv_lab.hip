@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include "gemv_w4_mfma.h"
 
 using namespace qeft;
@@ -27,6 +28,18 @@ __global__ __launch_bounds__(256) void stream_read(const u32x4* __restrict__ p, 
 
 struct Layer { void *qw, *sc, *sz, *ow; };
 
+__global__ void fill_random(uint32_t* p, size_t n, uint32_t seed, uint32_t andmask, uint32_t ormask) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = (uint32_t)i * 2654435761u ^ seed;
+    v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+    p[i] = (v & andmask) | ormask;
+}
+static void rnd(void* p, size_t bytes, uint32_t seed, uint32_t andmask = 0xffffffffu, uint32_t ormask = 0) {
+    size_t n = bytes / 4;
+    hipLaunchKernelGGL(fill_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t*)p, n, seed, andmask, ormask);
+}
+
 template <typename F>
 float time_launches(int reps, int L, F f) {
     hipEvent_t e0, e1;
@@ -48,30 +61,71 @@ void run_variant(const char* name, std::vector<Layer>& Ls, void* x, void* y, int
     size_t smem = gemv_smem_bytes(NW, RGI, 1, K, 128, 128);
     auto f = [&](int l) {
         GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l].qw, (const f16*)Ls[l].sc, (const f16*)Ls[l].sz, (const f16*)Ls[l].ow,
-                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f};
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f, nullptr, nullptr};
         hipLaunchKernelGGL(kern, dim3(N / (4 * RGI)), dim3(NW * 64), smem, 0, a);
     };
     float us = time_launches(20, L, f);
     printf("  %-20s NW=%d RGI=%d D=%d ABL=%2d : %7.2f us  %6.0f GB/s\n", name, NW, RGI, D, ABL, us, bytes / us / 1e3);
 }
 
-template <int NW, int D, int ABL>
-void run_mfma(const char* name, std::vector<Layer>& Ls, void* x, void* y, int N, int K, double bytes) {
+template <int NW, int D, int ABL, int XT = 0>
+void run_mfma(const char* name, std::vector<Layer>& Ls, void* x, void* y, int N, int K, double bytes, int nblk = 0) {
     const int L = (int)Ls.size();
-    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, 0, ABL>;
-    size_t smem = gemv_mfma_smem_bytes(NW, 1, K, 128);
+    const int nsets = N / 16;
+    if (nblk <= 0 || nblk > nsets) nblk = nsets;
+    const int rs_cap = (nsets + nblk - 1) / nblk;
+    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, XT, ABL>;
+    size_t smem = gemv_mfma_smem_bytes(NW, 1, K, 128, rs_cap);
+    if (smem > 64 * 1024) return;
     auto f = [&](int l) {
         GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l].qw, (const f16*)Ls[l].sc, (const f16*)Ls[l].sz, (const f16*)Ls[l].ow,
-                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f};
-        hipLaunchKernelGGL(kern, dim3(N / 16), dim3(NW * 64), smem, 0, a);
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, XT ? (const f16*)x : nullptr, 1e-5f, nullptr, nullptr};
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, a, rs_cap);
     };
     float us = time_launches(20, L, f);
-    printf("  %-20s MFMA NW=%d D=%d ABL=%2d : %7.2f us  %6.0f GB/s\n", name, NW, D, ABL, us, bytes / us / 1e3);
+    printf("  %-20s MFMA NW=%d D=%d blocks=%4d XT=%d ABL=%2d : %7.2f us  %6.0f GB/s\n", name, NW, D, nblk, XT, ABL, us, bytes / us / 1e3);
+}
+
+// one launch with per-wave stamps: block lifetime and phase boundaries
+template <int NW, int D, int XT>
+void timeline(std::vector<Layer>& Ls, void* x, void* y, int N, int K, int nblk) {
+    const int nsets = N / 16;
+    if (nblk <= 0 || nblk > nsets) nblk = nsets;
+    const int rs_cap = (nsets + nblk - 1) / nblk;
+    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, XT, 16>;
+    size_t smem = gemv_mfma_smem_bytes(NW, 1, K, 128, rs_cap);
+    if (smem > 64 * 1024) return;
+    unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)nblk * NW * 8 * 8));
+    std::vector<unsigned long long> h((size_t)nblk * NW * 8);
+    for (int rep = 0; rep < 3; ++rep) {
+        GemvArgs a{(const f16*)x, (const uint8_t*)Ls[rep].qw, (const f16*)Ls[rep].sc, (const f16*)Ls[rep].sz, (const f16*)Ls[rep].ow,
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, XT ? (const f16*)x : nullptr, 1e-5f, nullptr, dbg};
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, a, rs_cap);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t i = 0; i < h.size(); i += 8) { if (h[i] < t0) t0 = h[i]; if (h[i + 1] > t1) t1 = h[i + 1]; }
+    // realtime counter: 100 MHz -> 10 ns ticks
+    double span_us = (t1 - t0) * 0.01;
+    std::vector<double> life, ph[5], start;
+    for (size_t i = 0; i < h.size(); i += 8) {
+        life.push_back((h[i + 1] - h[i]) * 0.01);
+        start.push_back((h[i] - t0) * 0.01);
+        for (int p = 0; p < 5; ++p) ph[p].push_back((double)(h[i + 3 + p] - h[i + 2 + p]));
+    }
+    auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    auto mx = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() - 1]; };
+    printf("  timeline N=%d K=%d D=%d blocks=%d XT=%d: kernel span %.2f us; wave life median %.2f us max %.2f; start median %.2f max %.2f us\n",
+           N, K, D, nblk, XT, span_us, med(life), mx(life), med(start), mx(start));
+    printf("    phase cycles (median): issue-loads %.0f | transform+stage+barrier %.0f | steps %.0f | final barrier %.0f | store %.0f\n",
+           med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]));
+    CK(hipFree(dbg));
 }
 
 int main(int argc, char** argv) {
     const int L = 12;
-    int shapes[3][2] = {{4096, 4096}, {11008, 4096}, {4096, 11008}};
+    int shapes[4][2] = {{4096, 4096}, {11008, 4096}, {22016, 4096}, {4096, 11008}};
     uint32_t* out; CK(hipMalloc(&out, 4096));
     // ---- streaming ceilings
     {
@@ -93,25 +147,24 @@ int main(int argc, char** argv) {
         const int N = sh[0], K = sh[1];
         std::vector<Layer> Ls(L);
         for (auto& l : Ls) {
-            CK(hipMalloc(&l.qw, (size_t)N * K / 2)); CK(hipMemset(l.qw, 0x5a, (size_t)N * K / 2));
-            CK(hipMalloc(&l.sc, (size_t)K / 128 * N * 2)); CK(hipMemset(l.sc, 0x1c, (size_t)K / 128 * N * 2));
-            CK(hipMalloc(&l.sz, (size_t)K / 128 * N * 2)); CK(hipMemset(l.sz, 0x9c, (size_t)K / 128 * N * 2));
-            CK(hipMalloc(&l.ow, (size_t)N * 128 * 2)); CK(hipMemset(l.ow, 0x1c, (size_t)N * 128 * 2));
+            CK(hipMalloc(&l.qw, (size_t)N * K / 2)); rnd(l.qw, (size_t)N * K / 2, 17);
+            CK(hipMalloc(&l.sc, (size_t)K / 128 * N * 2)); rnd(l.sc, (size_t)K / 128 * N * 2, 3, 0x03ff03ffu, 0x1c001c00u);
+            CK(hipMalloc(&l.sz, (size_t)K / 128 * N * 2)); rnd(l.sz, (size_t)K / 128 * N * 2, 5, 0x03ff03ffu, 0xa400a400u);
+            CK(hipMalloc(&l.ow, (size_t)N * 128 * 2)); rnd(l.ow, (size_t)N * 128 * 2, 7, 0x83ff83ffu, 0x20002000u);
         }
-        void *x, *y; CK(hipMalloc(&x, K * 2)); CK(hipMemset(x, 0x3c, K * 2)); CK(hipMalloc(&y, N * 2));
+        void *x, *y; CK(hipMalloc(&x, K * 2)); rnd(x, K * 2, 9, 0x83ff83ffu, 0x38003800u); CK(hipMalloc(&y, N * 2));
         double bytes = (double)N * (K - 128) / 2 + 2.0 * (K / 128) * N * 2 + (double)N * 128 * 2 + 2 * K + 2 * N;
         printf("N=%d K=%d algorithmic bytes %.0f\n", N, K, bytes);
-        run_variant<8, 4, 2, 0>("valu full", Ls, x, y, N, K, bytes);
-        run_variant<8, 4, 4, 0>("valu full", Ls, x, y, N, K, bytes);
-        run_mfma<8, 2, 0>("mfma full", Ls, x, y, N, K, bytes);
-        run_mfma<8, 4, 0>("mfma full", Ls, x, y, N, K, bytes);
-        run_mfma<8, 6, 0>("mfma full", Ls, x, y, N, K, bytes);
-        run_mfma<4, 4, 0>("mfma full", Ls, x, y, N, K, bytes);
-        run_mfma<8, 2, 8>("mfma no xcd remap", Ls, x, y, N, K, bytes);
-        run_mfma<8, 4, 8>("mfma no xcd remap", Ls, x, y, N, K, bytes);
-        run_mfma<8, 4, 1>("mfma no scale ld", Ls, x, y, N, K, bytes);
-        run_mfma<8, 4, 4>("mfma no math", Ls, x, y, N, K, bytes);
-        run_mfma<8, 4, 5>("mfma no math/sc", Ls, x, y, N, K, bytes);
+        for (int nb : {0, 1024, 768, 512, 384, 256}) {
+            if (nb > N / 16) continue;
+            run_mfma<8, 4, 0, 1>("mfma +rmsnorm", Ls, x, y, N, K, bytes, nb);
+            run_mfma<8, 6, 0, 1>("mfma +rmsnorm", Ls, x, y, N, K, bytes, nb);
+        }
+        run_mfma<8, 4, 0, 0>("mfma", Ls, x, y, N, K, bytes, 512);
+        run_mfma<8, 6, 0, 2>("mfma +silu", Ls, x, y, N, K, bytes, 512);
+        timeline<8, 4, 1>(Ls, x, y, N, K, 0);
+        timeline<8, 4, 1>(Ls, x, y, N, K, 512);
+        timeline<8, 6, 1>(Ls, x, y, N, K, 256);
         for (auto& l : Ls) { (void)hipFree(l.qw); (void)hipFree(l.sc); (void)hipFree(l.sz); (void)hipFree(l.ow); }
         (void)hipFree(x); (void)hipFree(y);
     }
