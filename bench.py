@@ -156,7 +156,7 @@ def main():
         achieved = bytes_per_launch / us_per_launch / 1e3  # GB/s
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "qeft::gemv_w4_group_kernel / gemv_w4_kernel (4 launches per layer)",
+                "kernel": "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel (4 launches per layer)",
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3)}
     except Exception as e:  # never lose the headline number because of the side measurement
         if rank == 0:

@@ -90,6 +90,7 @@ static int gemv_fused_impl(const void* x, const void* qweight, const void* scale
     a.xt_eps = 0.f;
     a.sz_blk = (const uint32_t*)sz_packed;
     a.dbg = nullptr;
+    a.dbg2 = nullptr;
     if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
@@ -238,6 +239,7 @@ int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, con
     a.xt_eps = 0.f;
     a.sz_blk = (const uint32_t*)sz_packed;
     a.dbg = nullptr;
+    a.dbg2 = nullptr;
     return finish(qeft::gemv_w4_silu_dispatch(a, (hipStream_t)stream));
 }
 

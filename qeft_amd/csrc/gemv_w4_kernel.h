@@ -390,6 +390,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_group_kernel(GemvGroupArgs g)
     a.xt_eps = g.xt_eps;
     a.sz_blk = nullptr;
     a.dbg = nullptr;
+    a.dbg2 = nullptr;
     gemv_w4_body<NW, RGI, M, D, OUTL, false, 0, XT>(a, blk);
 }
 

@@ -33,6 +33,16 @@ __host__ __device__ constexpr size_t gemv_mfma_smem_bytes(int NW, int M, int K, 
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
+// Sum over the 16 lanes of a DPP row with 4 VALU DPP adds (quad swaps, half-row mirror, row mirror); every lane ends
+// with the row's total.  ds_bpermute-based __shfl_xor costs ~100 cycles per step and sits on the prologue's critical path.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 // A block owns RS consecutive 16-row sets (run time).  The block prologue (x staging, optional RMSNorm / SiLU,
 // correction sums) is paid once per block, so wide layers are launched with fewer, longer-lived blocks (a few per
 // CU): one prologue then feeds RS x more weight bytes, and a wave walks its (row set, step) pairs as ONE sequence so
@@ -63,7 +73,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     const int nsw = (nfull - wave + kWaves - 1) / kWaves;
     const bool per_channel = a.gshift == 31;
     // diagnostic stamps (lab builds only): [block][8] = realtime at entry, shader clock at the phase boundaries
-    unsigned long long stamp[6];
+    unsigned long long stamp[10];
     auto mark = [&](int i) {
         if (ABL & 16) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     };
@@ -81,9 +91,11 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     if (!XG) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
-            xst[p] = *(const u32x4*)(a.x + e);
-            if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
+            if (p == 0 || p * kBlock < xvecs) {           // block-uniform: passes beyond the row are not loaded at all
+                const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
+                xst[p] = *(const u32x4*)(a.x + e);
+                if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
+            }
         }
     }
     const int slab_vecs = OUTL ? RS * 8 * (2 * a.n_out) / 8 : 0;      // 8 interleaved rows of 2*n_out halves per row set
@@ -91,7 +103,8 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     u32x4 ost[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     if (OUTL) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) ost[p] = *(const u32x4*)(osrc + (size_t)min(p * kBlock + tid, slab_vecs - 1) * 8);
+        for (int p = 0; p < 2; ++p)
+            if (p == 0 || p * kBlock < slab_vecs) ost[p] = *(const u32x4*)(osrc + (size_t)min(p * kBlock + tid, slab_vecs - 1) * 8);
     }
     const int ngroups = per_channel ? 1 : nsteps;
     const int szn = ngroups * 8 * RS;                                  // dword pairs of two adjacent rows
@@ -102,7 +115,8 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     if (a.sz_blk) {
         // contiguous [RS][K/G][16] dwords for this block: coalesced 16-byte loads
 #pragma unroll
-        for (int p = 0; p < 2; ++p) szv[p] = *(const u32x4*)(szsrc + (size_t)min(p * kBlock + tid, szvecs - 1) * 4);
+        for (int p = 0; p < 2; ++p)
+            if (p == 0 || p * kBlock < szvecs) szv[p] = *(const u32x4*)(szsrc + (size_t)min(p * kBlock + tid, szvecs - 1) * 4);
     } else {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -145,33 +159,39 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
                     ss += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
                 }
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        mark(6);
+        ss = row16_sum(ss);
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
         if (lane == 0) red[wave] = ss;
-        __syncthreads();
+        __syncthreads();   // red is next written by flush(), i.e. after the staging barrier: no second barrier needed
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) tot += red[w];
         const float rs = rsqrtf(tot / (float)a.K + a.xt_eps);
-        __syncthreads();
 #pragma unroll
         for (int p = 0; p < 4; ++p)
+            if (p == 0 || p * kBlock < xvecs) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const h2 t = as_h2(xst[p][j]), gm = as_h2(ast[p][j]);
-                xst[p][j] = as_u32(h2{(f16)((float)t[0] * rs * (float)gm[0]), (f16)((float)t[1] * rs * (float)gm[1])});
+                for (int j = 0; j < 4; ++j) {
+                    const h2 t = as_h2(xst[p][j]), gm = as_h2(ast[p][j]);
+                    xst[p][j] = as_u32(h2{(f16)((float)t[0] * rs * (float)gm[0]), (f16)((float)t[1] * rs * (float)gm[1])});
+                }
             }
     } else if (XT == 2) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
+            if (p == 0 || p * kBlock < xvecs) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
-                const float g0 = (float)t[0], g1 = (float)t[1];
-                xst[p][j] = as_u32(h2{(f16)(g0 / (1.f + __expf(-g0)) * (float)u[0]), (f16)(g1 / (1.f + __expf(-g1)) * (float)u[1])});
+                for (int j = 0; j < 4; ++j) {
+                    const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
+                    const float g0 = (float)t[0], g1 = (float)t[1];
+                    xst[p][j] = as_u32(h2{(f16)(g0 / (1.f + __expf(-g0)) * (float)u[0]), (f16)(g1 / (1.f + __expf(-g1)) * (float)u[1])});
+                }
             }
     }
 
+    mark(7);
     // ---- 3. stage scales, x' (+ per-step sums) and the outlier slab into LDS
     if (a.sz_blk) {
         for (int v = tid; v < szvecs; v += kBlock) {
@@ -231,12 +251,9 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             uint32_t* dst = xs32 + (size_t)(e >> 5) * 16 + q;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i * 4] = xv[i];
-            // the 16 vectors of a 128-k step sit in 16 consecutive lanes
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                asum += __shfl_xor(asum, o);
-                bsum += __shfl_xor(bsum, o);
-            }
+            // the 16 vectors of a 128-k step sit in the 16 lanes of one DPP row
+            asum = row16_sum(asum);
+            bsum = row16_sum(bsum);
             if ((v & 15) == 0) {
                 corr[(e >> 7) * 2] = 1024.f * asum;
                 corr[(e >> 7) * 2 + 1] = bsum;
@@ -264,7 +281,15 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             }
         }
     }
+    mark(8);
     __syncthreads();
+    if (ABL & 32) {   // lab experiment: start the weight stream only after the staging loads have returned
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            issue(ring[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     mark(2);
 
     // ---- 4. steps
@@ -394,6 +419,13 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         d[1] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int i = 0; i < 6; ++i) d[2 + i] = stamp[i];
+        if (a.dbg2) {
+            unsigned long long* e = a.dbg2 + ((size_t)blockIdx.x * kWaves + wave) * 4;
+            e[0] = stamp[6] - stamp[1];   // loads issued -> x usable (sum of squares computed)
+            e[1] = stamp[7] - stamp[6];   // block reduction + normalisation
+            e[2] = stamp[8] - stamp[7];   // staging writes (scales, x', sums, slab)
+            e[3] = stamp[2] - stamp[8];   // barrier
+        }
     }
 }
 
@@ -449,6 +481,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupAr
     a.xt_eps = g.xt_eps;
     a.sz_blk = g.sz_blk[p];
     a.dbg = nullptr;
+    a.dbg2 = nullptr;
     int set0, cnt;
     block_sets(blk, nb, a.N / 16, set0, cnt);
     gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0>(a, set0, cnt, rs_cap);

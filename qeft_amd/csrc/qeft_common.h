@@ -64,6 +64,7 @@ struct GemvArgs {
     float xt_eps;
     const uint32_t* sz_blk;  // optional shadow [N/16][K/G][16] of (scale | scaled_zero << 16), see qeft_pack_scales
     unsigned long long* dbg; // tools/gemv_lab.hip only (ABL & 16): per-block time stamps; always NULL in the product
+    unsigned long long* dbg2;
 };
 
 struct GemvGroupArgs {

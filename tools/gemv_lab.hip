@@ -61,7 +61,7 @@ void run_variant(const char* name, std::vector<Layer>& Ls, void* x, void* y, int
     size_t smem = gemv_smem_bytes(NW, RGI, 1, K, 128, 128);
     auto f = [&](int l) {
         GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l].qw, (const f16*)Ls[l].sc, (const f16*)Ls[l].sz, (const f16*)Ls[l].ow,
-                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f, nullptr, nullptr};
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, nullptr, 0.f, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(kern, dim3(N / (4 * RGI)), dim3(NW * 64), smem, 0, a);
     };
     float us = time_launches(20, L, f);
@@ -79,7 +79,7 @@ void run_mfma(const char* name, std::vector<Layer>& Ls, void* x, void* y, int N,
     if (smem > 64 * 1024) return;
     auto f = [&](int l) {
         GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l].qw, (const f16*)Ls[l].sc, (const f16*)Ls[l].sz, (const f16*)Ls[l].ow,
-                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, XT ? (const f16*)x : nullptr, 1e-5f, nullptr, nullptr};
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, XT ? (const f16*)x : nullptr, 1e-5f, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, a, rs_cap);
     };
     float us = time_launches(20, L, f);
@@ -87,19 +87,20 @@ void run_mfma(const char* name, std::vector<Layer>& Ls, void* x, void* y, int N,
 }
 
 // one launch with per-wave stamps: block lifetime and phase boundaries
-template <int NW, int D, int XT>
+template <int NW, int D, int XT, int TLABL = 16>
 void timeline(std::vector<Layer>& Ls, void* x, void* y, int N, int K, int nblk) {
     const int nsets = N / 16;
     if (nblk <= 0 || nblk > nsets) nblk = nsets;
     const int rs_cap = (nsets + nblk - 1) / nblk;
-    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, XT, 16>;
+    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, XT, TLABL>;
     size_t smem = gemv_mfma_smem_bytes(NW, 1, K, 128, rs_cap);
     if (smem > 64 * 1024) return;
-    unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)nblk * NW * 8 * 8));
+    unsigned long long *dbg, *dbg2; CK(hipMalloc(&dbg, (size_t)nblk * NW * 8 * 8)); CK(hipMalloc(&dbg2, (size_t)nblk * NW * 4 * 8));
+    CK(hipMemset(dbg2, 0, (size_t)nblk * NW * 4 * 8));
     std::vector<unsigned long long> h((size_t)nblk * NW * 8);
     for (int rep = 0; rep < 3; ++rep) {
         GemvArgs a{(const f16*)x, (const uint8_t*)Ls[rep].qw, (const f16*)Ls[rep].sc, (const f16*)Ls[rep].sz, (const f16*)Ls[rep].ow,
-                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, XT ? (const f16*)x : nullptr, 1e-5f, nullptr, dbg};
+                   nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, XT ? (const f16*)x : nullptr, 1e-5f, nullptr, dbg, dbg2};
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, a, rs_cap);
         CK(hipDeviceSynchronize());
     }
@@ -120,7 +121,14 @@ void timeline(std::vector<Layer>& Ls, void* x, void* y, int N, int K, int nblk) 
            N, K, D, nblk, XT, span_us, med(life), mx(life), med(start), mx(start));
     printf("    phase cycles (median): issue-loads %.0f | transform+stage+barrier %.0f | steps %.0f | final barrier %.0f | store %.0f\n",
            med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]));
-    CK(hipFree(dbg));
+    {
+        std::vector<unsigned long long> h2((size_t)nblk * NW * 4);
+        CK(hipMemcpy(h2.data(), dbg2, h2.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> q[4];
+        for (size_t i = 0; i < h2.size(); i += 4) for (int p = 0; p < 4; ++p) q[p].push_back((double)(long long)h2[i + p]);
+        printf("    stage detail (median cycles): wait-x+sumsq %.0f | reduce+normalise %.0f | staging writes %.0f | barrier %.0f\n", med(q[0]), med(q[1]), med(q[2]), med(q[3]));
+    }
+    CK(hipFree(dbg)); CK(hipFree(dbg2));
 }
 
 int main(int argc, char** argv) {
@@ -155,16 +163,10 @@ int main(int argc, char** argv) {
         void *x, *y; CK(hipMalloc(&x, K * 2)); rnd(x, K * 2, 9, 0x83ff83ffu, 0x38003800u); CK(hipMalloc(&y, N * 2));
         double bytes = (double)N * (K - 128) / 2 + 2.0 * (K / 128) * N * 2 + (double)N * 128 * 2 + 2 * K + 2 * N;
         printf("N=%d K=%d algorithmic bytes %.0f\n", N, K, bytes);
-        for (int nb : {0, 1024, 768, 512, 384, 256}) {
-            if (nb > N / 16) continue;
-            run_mfma<8, 4, 0, 1>("mfma +rmsnorm", Ls, x, y, N, K, bytes, nb);
-            run_mfma<8, 6, 0, 1>("mfma +rmsnorm", Ls, x, y, N, K, bytes, nb);
-        }
-        run_mfma<8, 4, 0, 0>("mfma", Ls, x, y, N, K, bytes, 512);
-        run_mfma<8, 6, 0, 2>("mfma +silu", Ls, x, y, N, K, bytes, 512);
-        timeline<8, 4, 1>(Ls, x, y, N, K, 0);
-        timeline<8, 4, 1>(Ls, x, y, N, K, 512);
-        timeline<8, 6, 1>(Ls, x, y, N, K, 256);
+        const int nb = N / 16 < 512 ? N / 16 : 256 * ((N / 16 + 384) / 768);
+        run_mfma<8, 4, 0, 1>("mfma +rmsnorm", Ls, x, y, N, K, bytes, nb);
+        timeline<8, 4, 1, 16>(Ls, x, y, N, K, nb);
+        timeline<8, 4, 0, 16>(Ls, x, y, N, K, nb);
         for (auto& l : Ls) { (void)hipFree(l.qw); (void)hipFree(l.sc); (void)hipFree(l.sz); (void)hipFree(l.ow); }
         (void)hipFree(x); (void)hipFree(y);
     }
