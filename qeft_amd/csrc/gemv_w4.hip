@@ -69,7 +69,8 @@ static hipError_t launch_r(const GemvArgs& a, int m, hipStream_t st) {
 
 // ---- MFMA formulation (gemv_w4_mfma.h): the production path for the Llama shapes
 static bool mfma_ok(int N, int K, int G, int n_out) {
-    return K % 128 == 0 && n_out % 128 == 0 && (G == 128 || G == K) && N % 16 == 0 && N / 16 >= 128;
+    // no lower bound on N: a row's arithmetic must not depend on how many rows share its launch (row-sharding, §8e)
+    return K % 128 == 0 && n_out % 128 == 0 && (G == 128 || G == K) && N % 16 == 0;
 }
 
 // Blocks for a layer with `nsets` 16-row sets.  Every block pays ~1 us of start-up plus the x staging before its

@@ -145,3 +145,22 @@ def test_checkpoint_roundtrip_and_finetuned_delta(tmp_path):
     torch.cuda.synchronize()
     assert rel_err(y1.cpu().numpy(), (x.float() @ w0.T).numpy()) < REL_TOL
     assert not torch.allclose(y0, y1)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("m", [1, 3, 16])
+def test_row_shards_on_gpu_concatenate_to_full_output(world, m):
+    """sharded output == single-GPU output.  Every shard runs the same HIP kernels on its rows; the
+    concatenation (what the all-gather produces) must equal the full layer's output bit for bit."""
+    from qeft_amd.sharded import shard_quantlinear
+    n, k, r, g = 2048, 1024, 128, 128
+    full, bufs, _ = build(n, k, r, g, "model.layers.0.mlp.up_proj", bias=True, seed=8)
+    x = torch.from_numpy(O.make_activation(m, k, r, seed=m)).to(DEV)
+    y_full = full(x)
+    parts = [shard_quantlinear(full, rank, world).to(DEV)(x) for rank in range(world)]
+    torch.cuda.synchronize()
+    y = torch.cat(parts, dim=-1)
+    assert torch.equal(y, y_full)
+    yref = O.quant_linear(x.cpu().numpy(), bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"],
+                          bufs["bias"], g).astype(np.float64)
+    assert rel_err(y.detach().cpu().numpy(), yref) < REL_TOL
