@@ -9,6 +9,7 @@ namespace qeft {
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
 hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
 hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st);
+hipError_t gemv_w4_smallm_dispatch(const GemvArgs& a, int m, hipStream_t st);
 hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int H,
                           float eps, hipStream_t st);
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
@@ -28,6 +29,7 @@ hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, 
 }  // namespace qeft
 
 static thread_local int g_last_hip_error = 0;
+static const int kSmallM = 48;   // rows up to which the GEMM entry uses the MFMA GEMV (measured crossover)
 
 static int finish(hipError_t e) {
     if (e == hipSuccess) return QEFT_OK;
@@ -91,6 +93,8 @@ static int gemv_fused_impl(const void* x, const void* qweight, const void* scale
     a.sz_blk = (const uint32_t*)sz_packed;
     a.dbg = nullptr;
     a.dbg2 = nullptr;
+    a.ow_plain = nullptr;
+    a.m_rt = 1;
     if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
@@ -126,6 +130,28 @@ int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const v
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
+    if (m <= kSmallM && (n_out > 0) == (oweight != nullptr)) {
+        // few rows: stream the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
+        // (gemm_4bit semantics with oweight == NULL and a non-zero slice -- dead nibbles -- stays on the GEMM kernel.)
+        qeft::GemvArgs a{};
+        a.x = (const qeft::f16*)x;
+        a.qw = (const uint8_t*)qweight;
+        a.scales = (const qeft::f16*)scales;
+        a.zeros = (const qeft::f16*)scaled_zeros;
+        a.ow_il = nullptr;
+        a.ow_plain = (const qeft::f16*)oweight;
+        a.bias = (const qeft::f16*)bias;
+        a.y = (qeft::f16*)y;
+        a.N = n;
+        a.K = k;
+        a.G = group_size;
+        a.n_out = n_out;
+        a.gshift = (group_size == k) ? 31 : ((group_size & (group_size - 1)) == 0 ? __builtin_ctz(group_size) : 0);
+        a.m_rt = 1;
+        const hipError_t e = qeft::gemv_w4_smallm_dispatch(a, m, (hipStream_t)stream);
+        if (e == hipSuccess) return QEFT_OK;
+        if (e != hipErrorNotSupported) return finish(e);
+    }
     return finish(qeft::gemm_w4_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out,
                                        (hipStream_t)stream));
 }
@@ -240,6 +266,8 @@ int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, con
     a.sz_blk = (const uint32_t*)sz_packed;
     a.dbg = nullptr;
     a.dbg2 = nullptr;
+    a.ow_plain = nullptr;
+    a.m_rt = 1;
     return finish(qeft::gemv_w4_silu_dispatch(a, (hipStream_t)stream));
 }
 

@@ -128,6 +128,47 @@ static hipError_t launch_mfma_m(const GemvArgs& a, int m, hipStream_t st) {
 }
 
 // ring depth (steps in flight per wave), measured with tools/gemv_lab.hip: short rows want 2, long rows 6
+static int mfma_depth(int K);
+// Small-M route of the GEMM entry (8 <= M <= ~128): the MFMA GEMV contracts up to 16 batch rows per pass at the
+// cost of one weight stream, far cheaper than a 128-row GEMM tile at these sizes.  Processes rows in slices of <= 16.
+hipError_t gemv_w4_smallm_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
+    if (!mfma_ok(a0.N, a0.K, a0.G, a0.n_out)) return hipErrorNotSupported;
+    int mmax = 16;
+    while (mmax > 4 && gemv_mfma_smem_bytes(kNW, mmax, a0.K, a0.n_out) > kMaxLds) --mmax;
+    if (gemv_mfma_smem_bytes(kNW, mmax, a0.K, a0.n_out) > kMaxLds) return hipErrorNotSupported;
+    const int nsets = a0.N / 16;
+    for (int m0 = 0; m0 < m; m0 += mmax) {
+        GemvArgs a = a0;
+        a.m_rt = (m - m0 < mmax) ? m - m0 : mmax;
+        a.x = a0.x + (size_t)m0 * a0.K;
+        a.y = a0.y + (size_t)m0 * a0.N;
+        if (a.m_rt < 4) {   // tail slice: the fixed-M kernels (M = 1..3)
+            a.ow_plain = a0.ow_plain;
+            GemvArgs b = a;
+            hipError_t e = b.m_rt == 1 ? launch_mfma<1, 4>(b, st) : b.m_rt == 2 ? launch_mfma<2, 4>(b, st) : launch_mfma<3, 4>(b, st);
+            if (e != hipSuccess) return e;
+            continue;
+        }
+        const size_t smem = gemv_mfma_smem_bytes(kNW, a.m_rt, a.K, a.n_out);
+        const dim3 grid(nsets), block(kNW * 64);
+        hipError_t e = hipSuccess;
+        if (a.n_out > 0) {
+            auto kern = gemv_w4_mfma_kernel<kNW, 16, 4, true, false, 0, 0>;
+            if (smem > 64 * 1024) e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, block, smem, st, a, 1);
+        } else {
+            auto kern = gemv_w4_mfma_kernel<kNW, 16, 4, false, false, 0, 0>;
+            if (smem > 64 * 1024) e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, block, smem, st, a, 1);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 static int mfma_depth(int K) { return K > 6144 ? 6 : 4; }
 
 // Row-groups per wave-load: 4 (16 rows per block) when that still gives >= 1 block per CU, fewer for small

@@ -391,6 +391,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_group_kernel(GemvGroupArgs g)
     a.sz_blk = nullptr;
     a.dbg = nullptr;
     a.dbg2 = nullptr;
+    a.ow_plain = nullptr;
+    a.m_rt = 1;
     gemv_w4_body<NW, RGI, M, D, OUTL, false, 0, XT>(a, blk);
 }
 

@@ -52,14 +52,17 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     // this block owns the 16-row sets [set0, set0 + RS) of the layer; LDS is carved for rs_cap sets (launch constant)
     static_assert(XT == 0 || (M == 1 && !XG), "x transforms are for the batch-1 decode engine");
     constexpr int kWaves = NW, kBlock = NW * 64;
+    // M == 16 is the "any batch 4..16" instantiation used by the small-M GEMM route: the MFMA contracts 16 batch rows
+    // anyway, only LDS sizes and the stored rows depend on the real count a.m_rt.
+    const int MR = (M == 16) ? a.m_rt : M;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = (float*)smem;                                                    // [rs_cap][NW][M][16]
-    f16* slab = (f16*)(smem + rs_cap * NW * 16 * M * 4);                          // [rs_cap*16][n_out + 8]
+    f16* slab = (f16*)(smem + rs_cap * NW * 16 * MR * 4);                          // [rs_cap*16][n_out + 8]
     const int slab_stride = gemv_slab_stride(a.n_out);
     uint32_t* szl = (uint32_t*)(slab + (OUTL ? rs_cap * 16 * slab_stride : 0));   // [rs_cap][K/128][16]
     const int nsteps = a.K / 128;
     float* corr = (float*)(szl + rs_cap * nsteps * 16);
-    uint32_t* xs32 = (uint32_t*)((uint8_t*)corr + ((size_t)M * nsteps * 8 + 15) / 16 * 16);   // x' as dwords (k-pairs)
+    uint32_t* xs32 = (uint32_t*)((uint8_t*)corr + ((size_t)MR * nsteps * 8 + 15) / 16 * 16);   // x' as dwords (k-pairs)
     const f16* xs = (const f16*)xs32;
 
     const int tid = threadIdx.x;
@@ -82,7 +85,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     mark(0);
 
     // ---- 1. oldest loads: x, the transform operand, the outlier slab, the scales
-    const int xtotal = M * a.K;
+    const int xtotal = MR * a.K;
     const int xvecs = xtotal / 8;
     u32x4 xst[XG ? 1 : 4];
     u32x4 ast[XT ? 4 : 1];
@@ -99,9 +102,9 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         }
     }
     const int slab_vecs = OUTL ? RS * 8 * (2 * a.n_out) / 8 : 0;      // 8 interleaved rows of 2*n_out halves per row set
-    const f16* osrc = OUTL ? a.ow_il + (size_t)(rg0 >> 1) * 4 * (2 * a.n_out) : nullptr;
+    const f16* osrc = (OUTL && !a.ow_plain) ? a.ow_il + (size_t)(rg0 >> 1) * 4 * (2 * a.n_out) : nullptr;
     u32x4 ost[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    if (OUTL) {
+    if (OUTL && !a.ow_plain) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             if (p == 0 || p * kBlock < slab_vecs) ost[p] = *(const u32x4*)(osrc + (size_t)min(p * kBlock + tid, slab_vecs - 1) * 8);
@@ -260,7 +263,22 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             }
         }
     }
-    if (OUTL) {
+    if (OUTL && a.ow_plain) {
+        // plain oweight [N, n_out] (the GEMM entry's operand): a 16-byte piece = 8 columns (4 dwords) of one row
+        uint32_t* slab32 = (uint32_t*)slab;
+        const int sstr = slab_stride / 2;
+        const int per_row = a.n_out / 8;
+        for (int v = tid; v < RS * 16 * per_row; v += kBlock) {
+            const int lrow = v / per_row, piece = v % per_row;
+            const u32x4 ov = *(const u32x4*)(a.ow_plain + (size_t)(row0 + lrow) * a.n_out + piece * 8);
+            const int c32 = piece >> 2, d0 = (piece & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = d0 + i;
+                slab32[lrow * sstr + c32 * 16 + (d & 3) * 4 + (d >> 2)] = ov[i];
+            }
+        }
+    } else if (OUTL) {
         // pack_oweight layout (qlinear.py:70-79); a 16-byte piece = 4 columns (2 dwords) of rows blk*8+rr and +4.
         uint32_t* slab32 = (uint32_t*)slab;
         const int sstr = slab_stride / 2;   // dwords per slab row
@@ -296,7 +314,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};     // acc[j]: batch row m = 4*kc + j, weight row nl of the current row set
     uint32_t MAGIC = 0x64006400u;
     asm volatile("" : "+v"(MAGIC));
-    const int am = min(nl, M - 1);         // A-operand row of this lane (rows >= M replicate row M-1, never stored)
+    const int am = min(nl, MR - 1);         // A-operand row of this lane (rows >= M replicate row M-1, never stored)
     const f16* xa = xs + (size_t)am * a.K + kc * 32;
 
     // fp16 outlier steps [nfull, nsteps) of row set rs: B fragments straight from the LDS slab (same slot order)
@@ -315,7 +333,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = 4 * kc + j;
-            if (m < M) red[((rs * kWaves + wave) * M + m) * 16 + nl] = acc[j];
+            if (m < MR) red[((rs * kWaves + wave) * MR + m) * 16 + nl] = acc[j];
         }
         acc = f32x4{0.f, 0.f, 0.f, 0.f};
     };
@@ -337,7 +355,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         o.szw = szl[(rs * nsteps + (per_channel ? 0 : s)) * 16 + nl];
 #pragma unroll
         for (int j = 0; j < (M < 4 ? M : 4); ++j) {       // batch row m = 4*kc + j; rows >= M are never stored
-            const int m = min(4 * kc + j, M - 1);
+            const int m = min(4 * kc + j, MR - 1);
             o.ab[j] = *(const float2*)(corr + ((size_t)m * nsteps + s) * 2);
         }
     };
@@ -402,11 +420,11 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     // ---- 5. combine the waves
     __syncthreads();
     mark(4);
-    for (int o = tid; o < RS * 16 * M; o += kBlock) {
-        const int rs = o / (16 * M), m = (o / 16) % M, n = o & 15;
+    for (int o = tid; o < RS * 16 * MR; o += kBlock) {
+        const int rs = o / (16 * MR), m = (o / 16) % MR, n = o & 15;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) v += red[((rs * kWaves + w) * M + m) * 16 + n];
+        for (int w = 0; w < kWaves; ++w) v += red[((rs * kWaves + w) * MR + m) * 16 + n];
         const int orow = row0 + rs * 16 + n;
         if (a.bias) v += (float)a.bias[orow];
         if (a.residual) v += (float)a.residual[(size_t)m * a.N + orow];
@@ -482,6 +500,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupAr
     a.sz_blk = g.sz_blk[p];
     a.dbg = nullptr;
     a.dbg2 = nullptr;
+    a.ow_plain = nullptr;
+    a.m_rt = 1;
     int set0, cnt;
     block_sets(blk, nb, a.N / 16, set0, cnt);
     gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0>(a, set0, cnt, rs_cap);

@@ -65,6 +65,8 @@ struct GemvArgs {
     const uint32_t* sz_blk;  // optional shadow [N/16][K/G][16] of (scale | scaled_zero << 16), see qeft_pack_scales
     unsigned long long* dbg; // tools/gemv_lab.hip only (ABL & 16): per-block time stamps; always NULL in the product
     unsigned long long* dbg2;
+    const f16* ow_plain;     // outlier slice as plain [N, n_out] rows instead of ow_il (small-M route of the GEMM entry)
+    int m_rt;                // real batch rows when the kernel is the M == 16 instantiation
 };
 
 struct GemvGroupArgs {
