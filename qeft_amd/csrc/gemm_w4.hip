@@ -18,6 +18,8 @@
 //     16-lane ds_read_b128 groups hit 16 distinct 16-byte bank groups.
 //   * k-tiles inside the last n_out columns take their B fragments from the fp16 oweight slice instead
 //     of the (dead) nibbles: same MFMA stream, no second kernel, no read-modify-write of y.
+#include <cstdlib>
+
 #include "qeft_common.h"
 
 namespace qeft {
@@ -171,9 +173,228 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel(const f16* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Forward GEMM, pipelined version (the one gemm_w4_launch uses whenever K has >= 4 k-tiles).
+//   * 128 x 128 x 64 block tile, 4 waves side by side along N (each 128 rows x 32 columns = 4 MFMA 32x32 tiles), so
+//     every weight is dequantised by exactly one wave.
+//   * Both operands reach LDS by LDS-DMA (global_load_lds, 16 B/lane, no VGPR round trip) into a ring of kStages
+//     tiles; kStages-1 tiles stay in flight behind a COUNTED s_waitcnt vmcnt and ONE raw s_barrier per k-tile.
+//     A keeps its natural k order (slot j of a 32-k chunk = 8 consecutive k = the A fragment of k-step j); B's
+//     dequantised pairs are written straight into the matching fragment registers (pair j of word w -> fragment j,
+//     position w).  Slots are XOR-swizzled with (row & 7) on the SOURCE address (the DMA destination is lane-linear).
+//   * scales / scaled zeros of the block's 128 columns are staged once into LDS as (s | sz << 16) words.
+//   * k-tiles inside the fp16 outlier slice take their B fragments straight from oweight (2 tiles for r = 128).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kStages = 3;
+constexpr int kTileBytes = BM * BK * 2 + BN * BK / 2;   // 16 KB of A + 4 KB of packed B
+
+__host__ __device__ constexpr size_t gemm_v2_smem(int K, int G) { return (size_t)kStages * kTileBytes + (size_t)(K / G) * BN * 4; }
+
+// LDS reads of DMA-written tiles go through inline asm: hipcc (ROCm 7.2) otherwise drains the whole DMA pipeline with
+// s_waitcnt vmcnt(0) before any ds_read that might alias an LDS-DMA in flight.  The loads are made visible to the
+// consumer only by lds_wait() (s_waitcnt lgkmcnt(0) + a scheduling barrier), guide section 5.7 form (iii).
+__device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_vm(int n) {   // counted wait: n outstanding vector-memory ops allowed
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
+}
+
+template <bool OUTL>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
+                                                                  const f16* __restrict__ scales,
+                                                                  const f16* __restrict__ zeros,
+                                                                  const f16* __restrict__ ow, const f16* __restrict__ bias,
+                                                                  f16* __restrict__ y, int M, int N, int K, int G,
+                                                                  int n_out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];     // [kStages][A 16 KB | B 4 KB] [sz]
+    uint32_t* szl = (uint32_t*)(lds + kStages * kTileBytes);          // [K/G][128]
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;                   // LDS byte address of the array (for the asm reads)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+    const int ktiles = K / BK;
+    const int kq = K - (OUTL ? n_out : 0);
+    const int qtiles = kq / BK;            // INT4 k-tiles [0, qtiles); outlier k-tiles [qtiles, ktiles) (n_out % 64 == 0)
+    const int ngroups = K / G;
+    const int gshift = 31 - __builtin_clz(G);    // G is a power of two on this path (checked by the launcher)
+
+    const int nloc = wave * 32 + r;
+    const int ncol = min(bn0 + nloc, N - 1);
+    const bool nok = bn0 + nloc < N;
+
+    // ---- scales of the block's columns -> LDS (once)
+    for (int i = tid; i < ngroups * BN; i += GEMM_THREADS) {
+        const int g = i / BN, c = min(bn0 + (i % BN), N - 1);
+        const uint32_t sv = ((const uint16_t*)scales)[(size_t)g * N + c], zv = ((const uint16_t*)zeros)[(size_t)g * N + c];
+        szl[i] = sv | (zv << 16);
+    }
+
+    // ---- DMA sources.  A: wave w, instruction i -> rows (w*4+i)*8 + lane/8, slot' = lane%8 holds chunk slot'^(row&7)
+    const f16* asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int grow = min(bm0 + row, M - 1);
+        asrc[i] = x + (size_t)grow * K + (((lane & 7) ^ (row & 7)) << 3);
+    }
+    const int brg = min(bn0 / 4 + (tid >> 3), N / 4 - 1);
+    const uint8_t* bsrc = qw + (size_t)brg * K * 2 + (tid & 7) * 16;
+
+    auto stage = [&](int t) {
+        uint8_t* base = lds + (t % kStages) * kTileBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[i] + (size_t)t * BK),
+                                             (void __attribute__((address_space(3)))*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(bsrc + (size_t)min(t, qtiles > 0 ? qtiles - 1 : 0) * 128),
+                                         (void __attribute__((address_space(3)))*)(base + BM * BK * 2 + wave * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // per-lane LDS offsets of the A fragments: m-tile mt, k-step j -> row*128 + ((h*4+j) ^ (row&7))*16
+    uint32_t aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ (r & 7)) << 4));   // (row & 7) == (r & 7): mt*32 keeps the low bits
+    const uint32_t boff = (uint32_t)(BM * BK * 2 + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);
+    const uint32_t szoff = (uint32_t)(kStages * kTileBytes + nloc * 4);
+
+    __syncthreads();   // scale words visible to every wave; no DMA is in flight yet, so the implied vmcnt(0) is free
+#pragma unroll
+    for (int t = 0; t < kStages - 1; ++t)
+        if (t < ktiles) stage(t);
+
+    auto mma_tile = [&](uint32_t tbase, const u32x4 (&bfrag)[4], u32x4 (&a0)[4]) {
+        u32x4 a1[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            // fetch the next m-tile's fragments while this one's MFMAs run
+            if (mt + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 v = lds_read16(tbase + (mt + 1) * 32 * 128 + aoff[j]);
+                    if (mt & 1) a0[j] = v; else a1[j] = v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (mt & 1) ? a1[j] : a0[j]),
+                                                                __builtin_bit_cast(h8, bfrag[j]), acc[mt], 0, 0, 0);
+            lds_wait();
+        }
+    };
+
+    // ---- main loop over the INT4 k-tiles: kStages-1 tiles in flight, one barrier per tile
+    for (int t = 0; t < qtiles; ++t) {
+        const int younger = min(qtiles - 1 - t, kStages - 2);
+        wait_vm(younger * 5);
+        __builtin_amdgcn_s_barrier();      // every wave's DMA for tile t landed; everyone is done reading tile t-1
+        if (t + kStages - 1 < qtiles) stage(t + kStages - 1);   // overwrites the buffer of tile t-1
+
+        const uint32_t tbase = lds0 + (uint32_t)(t % kStages) * kTileBytes;
+        const u32x4 q = lds_read16(tbase + boff);
+        const uint32_t szw = lds_read4(lds0 + szoff + (uint32_t)(((t * BK + h * 32) >> gshift) * BN * 4));
+        u32x4 a0[4];   // first m-tile's A fragments: in flight while B is dequantised
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a0[j] = lds_read16(tbase + aoff[j]);
+        lds_wait();
+        // B fragments: k-step j contracts the 8 CONSECUTIVE k h*32 + 8j .. +7 (= A's natural slot j); they are pair j of
+        // each of the 4 nibble words, so the dequantised pairs are written to fragment j, position w (a register naming).
+        u32x4 bfrag[4];
+        {
+            const h2 sz = as_h2(szw);
+            const h2 sc = splat(sz[0]), zc = splat(sz[1]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                h2 wd[4];
+                dequant8(q[w], sc, zc, wd);           // wd[j] = pair (k = 2w + 8j, 2w + 8j + 1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfrag[j][w] = as_u32(wd[j]);
+            }
+        }
+        mma_tile(tbase, bfrag, a0);
+    }
+
+    // ---- fp16 outlier k-tiles (2 for r = 128): pipeline is empty; A by DMA, B fragments straight from oweight
+    if (OUTL) {
+        for (int t = qtiles; t < ktiles; ++t) {
+            __builtin_amdgcn_s_barrier();          // all waves finished reading the buffers of earlier tiles
+            uint8_t* base = lds;                   // stage buffer 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[i] + (size_t)t * BK),
+                                                 (void __attribute__((address_space(3)))*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+            u32x4 bfrag[4];
+            const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + (t * BK + h * 32 - kq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfrag[j] = p[j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            u32x4 a0[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] = lds_read16(lds0 + aoff[j]);
+            lds_wait();
+            mma_tile(lds0, bfrag, a0);
+        }
+    }
+
+    if (nok) {
+        const float bv = bias ? (float)bias[ncol] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M) y[(size_t)m * N + ncol] = (f16)(acc[mt][e] + bv);
+            }
+    }
+}
+
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st) {
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    const bool outl = ow && n_out > 0;
+    const size_t smem2 = gemm_v2_smem(K, G);
+    if (K / BK >= kStages && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && smem2 <= 160 * 1024 &&
+        getenv("QEFT_GEMM_V1") == nullptr) {
+        if (outl) {
+            auto kern = gemm_w4_kernel_v2<true>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw, (const f16*)scales,
+                               (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G, n_out);
+        } else {
+            auto kern = gemm_w4_kernel_v2<false>;
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw, (const f16*)scales,
+                               (const f16*)zeros, (const f16*)nullptr, (const f16*)bias, (f16*)y, M, N, K, G, 0);
+        }
+        return hipGetLastError();
+    }
     if (ow && n_out > 0)
         hipLaunchKernelGGL(gemm_w4_kernel<true>, grid, dim3(GEMM_THREADS), 0, st, (const f16*)x, (const uint8_t*)qw,
                            (const f16*)scales, (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G,
