@@ -11,8 +11,9 @@
 // One wave-wide 16 B/lane load = 16 rows (4 row-groups) x 128 k.  Lane L loads the 16 bytes of row (L & 15), 32-k
 // chunk (L >> 4); its 4 words are the B fragments of 4 MFMAs, which together contract the step's 128 k for all 16
 // rows and up to 16 batch rows at once — no cross-lane reduction, and batch 1..7 cost the same.
-// The A operand is x, staged in LDS in the matching k-order (dwords {w, w+4, w+8, w+12} of a 32-k chunk form
-// 16-byte slot w), one ds_read_b128 per MFMA.
+// The A operand is x, staged in LDS in natural order: MFMA j of a step contracts the 8 consecutive k of 16-byte slot j
+// of the lane's chunk (one ds_read_b128), and the matching B fragment is pair j of each of the 4 nibble words --
+// a pure register naming of the v_and_or_b32 results.
 //
 // Arithmetic (identical to gemv_w4_kernel.h): nibbles become 1024+q / 1024+16q with one v_and_or_b32 each, x is
 // pre-multiplied by 1/16 where it meets high nibbles, and per step (= one quantisation group of 128 k)
@@ -25,10 +26,10 @@ namespace qeft {
 
 __host__ __device__ constexpr size_t gemv_mfma_smem_bytes(int NW, int M, int K, int n_out, int RS = 1) {
     return (size_t)RS * NW * 16 * M * 4 +                              // red   [RS][NW][M][16] f32
-           (n_out > 0 ? (size_t)RS * 16 * gemv_slab_stride(n_out) * 2 : 0) +  // slab  [RS*16][n_out+8] f16 (permuted slots)
+           (n_out > 0 ? (size_t)RS * 16 * gemv_slab_stride(n_out) * 2 : 0) +  // slab  [RS*16][n_out+8] f16
            (size_t)RS * (K / 128) * 16 * 4 +                            // szl   [RS][K/128][16] (s | sz << 16)
            ((size_t)M * (K / 128) * 8 + 15) / 16 * 16 +                 // corr  [M][K/128] (A, B) f32
-           (size_t)M * K * 2;                                           // xs    [M][K] f16 (permuted slots, prescaled)
+           (size_t)M * K * 2;                                           // xs    [M][K] f16 (natural order, prescaled)
 }
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
@@ -250,10 +251,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
                     asum += (float)t[0] + (float)t[1];
                 }
             }
-            // dword i of quarter q is natural dword 4q+i of the chunk -> slot i, position q
-            uint32_t* dst = xs32 + (size_t)(e >> 5) * 16 + q;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i * 4] = xv[i];
+            *(u32x4*)(xs32 + (size_t)(e >> 1)) = xv;      // natural order: slot q of the chunk
             // the 16 vectors of a 128-k step sit in the 16 lanes of one DPP row
             asum = row16_sum(asum);
             bsum = row16_sum(bsum);
@@ -271,12 +269,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         for (int v = tid; v < RS * 16 * per_row; v += kBlock) {
             const int lrow = v / per_row, piece = v % per_row;
             const u32x4 ov = *(const u32x4*)(a.ow_plain + (size_t)(row0 + lrow) * a.n_out + piece * 8);
-            const int c32 = piece >> 2, d0 = (piece & 3) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int d = d0 + i;
-                slab32[lrow * sstr + c32 * 16 + (d & 3) * 4 + (d >> 2)] = ov[i];
-            }
+            *(u32x4*)(slab32 + lrow * sstr + piece * 4) = ov;
         }
     } else if (OUTL) {
         // pack_oweight layout (qlinear.py:70-79); a 16-byte piece = 4 columns (2 dwords) of rows blk*8+rr and +4.
@@ -286,17 +279,12 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             const u32x4 ov = (v == tid) ? ost[0] : (v == tid + kBlock) ? ost[1] : *(const u32x4*)(osrc + (size_t)v * 8);
             const int per_row = (2 * a.n_out) / 8;
             const int ir = v / per_row, piece = v % per_row;
-            const int c32 = piece >> 3, d0 = (piece & 7) * 2;          // natural dwords d0, d0+1 of the chunk
-            const uint32_t lo[2] = {__builtin_amdgcn_perm(ov[1], ov[0], 0x05040100u), __builtin_amdgcn_perm(ov[3], ov[2], 0x05040100u)};
-            const uint32_t hi[2] = {__builtin_amdgcn_perm(ov[1], ov[0], 0x07060302u), __builtin_amdgcn_perm(ov[3], ov[2], 0x07060302u)};
+            const int d0 = (piece >> 3) * 16 + (piece & 7) * 2;          // natural dwords d0, d0+1 of the row
+            const u32x2 lo = {__builtin_amdgcn_perm(ov[1], ov[0], 0x05040100u), __builtin_amdgcn_perm(ov[3], ov[2], 0x05040100u)};
+            const u32x2 hi = {__builtin_amdgcn_perm(ov[1], ov[0], 0x07060302u), __builtin_amdgcn_perm(ov[3], ov[2], 0x07060302u)};
             const int lrow = (ir >> 2) * 8 + (ir & 3);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int d = d0 + i;
-                const int pos = c32 * 16 + (d & 3) * 4 + (d >> 2);      // slot d%4, position d/4
-                slab32[lrow * sstr + pos] = lo[i];
-                slab32[(lrow + 4) * sstr + pos] = hi[i];
-            }
+            *(u32x2*)(slab32 + lrow * sstr + d0) = lo;
+            *(u32x2*)(slab32 + (lrow + 4) * sstr + d0) = hi;
         }
     }
     mark(8);
@@ -369,13 +357,20 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             acc[0] += __builtin_bit_cast(float, wv[0] ^ wv[1] ^ wv[2] ^ wv[3]);
         } else {
             f32x4 P0 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};   // two chains: MFMA latency is exposed at 2 waves/SIMD
+            // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
+            u32x4 bf[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const uint32_t v = wv[w], t = v >> 8;
-                const u32x4 bw = {(v & 0x000f000fu) | MAGIC, (v & 0x00f000f0u) | MAGIC, (t & 0x000f000fu) | MAGIC,
-                                  (t & 0x00f000f0u) | MAGIC};
-                if (w & 1) P1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[w], __builtin_bit_cast(h8v, bw), P1, 0, 0, 0);
-                else P0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[w], __builtin_bit_cast(h8v, bw), P0, 0, 0, 0);
+                bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
+                bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q   (x' = x / 16 on these k)
+                bf[2][w] = (t & 0x000f000fu) | MAGIC;
+                bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j & 1) P1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[j], __builtin_bit_cast(h8v, bf[j]), P1, 0, 0, 0);
+                else P0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[j], __builtin_bit_cast(h8v, bf[j]), P0, 0, 0, 0);
             }
             const h2 szp = as_h2(cur.szw);
             const float sf = (float)szp[0], zf = (float)szp[1];
