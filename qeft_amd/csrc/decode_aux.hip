@@ -107,17 +107,42 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     f16* kch = kc + (size_t)hk * max_seq * HD;
     f16* vch = vc + (size_t)hk * max_seq * HD;
 
+    // Every cache byte this block needs is known as soon as `pos` is: the K quarter-rows and V pieces of the first 256
+    // positions are requested up front, right behind the token's own q/k/v and rotary entries, so the kernel pays two
+    // dependent memory round trips (pos, then everything) instead of four (pos, q/k/v, K rows, V rows).
+    const int qd = t & 3;
+    const int dg = t & 15, pg = t >> 4;
+    float rc = 0.f, rs = 0.f, ra = 0.f, rb = 0.f;
+    if (t < 128) {
+        const int i = t & 63;
+        rc = cs[(size_t)pos * 64 + i];
+        rs = sn[(size_t)pos * 64 + i];
+        const f16* src = (t < 64) ? q + h * HD : k + hk * HD;
+        ra = (float)src[i];
+        rb = (float)src[i + 64];
+    } else {
+        ra = (float)v[hk * HD + (t - 128)];
+    }
+    constexpr int KPRE = 4, VPRE = 16;          // 4 passes x 64 positions; 16 x 16 positions
+    h8 kpre[KPRE][4], vpre[VPRE];
+#pragma unroll
+    for (int i = 0; i < KPRE; ++i)
+        if (i * 64 < L) {                       // block-uniform
+            const h8* row = (const h8*)(kch + (size_t)min(i * 64 + (t >> 2), max_seq - 1) * HD + qd * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kpre[i][j] = row[j];
+        }
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i)
+        if (i * 16 < L) vpre[i] = *(const h8*)(vch + (size_t)min(pg + 16 * i, max_seq - 1) * HD + dg * 8);
+
     if (t < 64) {
-        const float c = cs[(size_t)pos * 64 + t], s = sn[(size_t)pos * 64 + t];
-        const float a = (float)q[h * HD + t], b = (float)q[h * HD + t + 64];
         const float scale = 0.08838834764831845f;  // 1/sqrt(128)
-        qs[t] = (a * c - b * s) * scale;
-        qs[t + 64] = (b * c + a * s) * scale;
+        qs[t] = (ra * rc - rb * rs) * scale;
+        qs[t + 64] = (rb * rc + ra * rs) * scale;
     } else if (t < 128) {
         const int i = t - 64;
-        const float c = cs[(size_t)pos * 64 + i], s = sn[(size_t)pos * 64 + i];
-        const float a = (float)k[hk * HD + i], b = (float)k[hk * HD + i + 64];
-        const f16 k0 = (f16)(a * c - b * s), k1 = (f16)(b * c + a * s);
+        const f16 k0 = (f16)(ra * rc - rb * rs), k1 = (f16)(rb * rc + ra * rs);
         knew[i] = k0;
         knew[i + 64] = k1;
         if (h % grp == 0) {
@@ -126,19 +151,18 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
         }
     } else {
         const int i = t - 128;
-        const f16 vv = v[hk * HD + i];
+        const f16 vv = (f16)ra;
         vnew[i] = vv;
         if (h % grp == 0) vch[(size_t)pos * HD + i] = vv;
     }
     __syncthreads();
 
     // scores: 4 lanes per position (32 dims each, q quarter kept in registers), 64 positions per pass
-    const int qd = t & 3;
     float qreg[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) qreg[j] = qs[qd * 32 + j];
     float lmax = -3.0e38f;
-    for (int p0 = 0; p0 < L; p0 += 64) {
+    auto score_pass = [&](int p0, const h8* kr) {
         const int p = p0 + (t >> 2);
         float s = 0.f;
         if (p < L) {
@@ -146,12 +170,10 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
 #pragma unroll
                 for (int j = 0; j < 32; ++j) s += qreg[j] * (float)knew[qd * 32 + j];
             } else {
-                const h8* row = (const h8*)(kch + (size_t)p * HD + qd * 32);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const h8 kv = row[j];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += qreg[j * 8 + e] * (float)kv[e];
+                    for (int e = 0; e < 8; ++e) s += qreg[j * 8 + e] * (float)kr[j][e];
                 }
             }
         }
@@ -161,6 +183,16 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
             if (qd == 0) sc[p] = s;
             lmax = fmaxf(lmax, s);
         }
+    };
+#pragma unroll
+    for (int i = 0; i < KPRE; ++i)
+        if (i * 64 < L) score_pass(i * 64, kpre[i]);
+    for (int p0 = KPRE * 64; p0 < L; p0 += 64) {
+        h8 kr[4];
+        const h8* row = (const h8*)(kch + (size_t)min(p0 + (t >> 2), max_seq - 1) * HD + qd * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kr[j] = row[j];
+        score_pass(p0, kr);
     }
     const float mx = block_max_256(lmax, sm);
     float lsum = 0.f;
@@ -172,17 +204,20 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     const float inv = 1.f / block_sum_256(lsum, sm);
     __syncthreads();
 
-    // P.V: thread = (8-dim group, 1 of 16 position classes); 16-byte V loads; partials combined through LDS
-    const int dg = t & 15, pg = t >> 4;
+    // P.V: thread = (8-dim group, 1 of 16 position classes); 16-byte V pieces; partials combined through LDS
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int p = pg; p < L; p += 16) {
-        const h8 vv = (p == pos) ? *(const h8*)(vnew + dg * 8) : *(const h8*)(vch + (size_t)p * HD + dg * 8);
+    auto pv = [&](int p, h8 vv) {
+        if (p == pos) vv = *(const h8*)(vnew + dg * 8);
         const float w = sc[p];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += w * (float)vv[e];
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i)
+        if (pg + 16 * i < L) pv(pg + 16 * i, vpre[i]);
+    for (int p = pg + 16 * VPRE; p < L; p += 16) pv(p, *(const h8*)(vch + (size_t)p * HD + dg * 8));
 #pragma unroll
     for (int e = 0; e < 8; ++e) part[pg * HD + dg * 8 + e] = o[e];
     __syncthreads();
