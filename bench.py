@@ -94,7 +94,7 @@ def main():
     from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, DecodeEngine, QuantLlama, tiny_shape
     import dataclasses
     base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B, "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
-    shape = dataclasses.replace(base, max_seq=max(512, args.warmup + args.steps + 8))
+    shape = dataclasses.replace(base, max_seq=max(512, (args.warmup + args.steps + 8 + 15) // 16 * 16))
 
     t_build = time.time()
     model = QuantLlama(shape, dev, seed=0, fast_init=True)

@@ -131,12 +131,27 @@ int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_strea
 
 /* One decode token of one sequence: rotary on q/k at position *pos (device int), append k/v to the caches
  * [n_kv][max_seq][128] and compute softmax(q.K^T/sqrt(128)).V (role of single_query_attention,
- * qeft/kernel/attention/ft_attention.cpp:110-181, neox rotary).  head_dim is 128. cos/sin: fp32 [max_seq][64].
+ * qeft/kernel/attention/ft_attention.cpp:110-181, neox rotary).  head_dim is 128, max_seq % 16 == 0.
+ * cos/sin: fp32 [tab_rows][64], tab_rows >= max_seq (row *pos is used), or tab_rows == 1: the caller has already
+ * selected the row of this position (the kernel then has no load that waits for *pos before the rotary).
  * out_pos (optional int32 [n_heads*128]): element i of the attention output is stored at out[out_pos[i]].  With
- * out_pos = inverse of o_proj's reorder_ids the o_proj input gather (qlinear.py:275) costs nothing. */
+ * out_pos = inverse of o_proj's reorder_ids the o_proj input gather (qlinear.py:275) costs nothing.
+ * n_split in {1, 2, 4, 8}: blocks per head (the context is dealt over them; the last block to finish merges the
+ * head, in a fixed order).  n_split > 1 needs `workspace`: qeft_attn_workspace_bytes(n_heads, n_split) bytes of
+ * device memory, 16-byte aligned, ZERO before the first call and not shared by launches that may overlap; the
+ * kernel leaves it ready for the next call. */
+int qeft_attn_workspace_bytes(int n_heads, int n_split);   /* 0 for n_split == 1 or bad arguments */
 int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
-                          void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out, int n_heads,
-                          int n_kv_heads, int max_seq, qeft_stream_t stream);
+                          int tab_rows, void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out,
+                          void* workspace, int n_split, int n_heads, int n_kv_heads, int max_seq, qeft_stream_t stream);
+
+/* Token boundary of the decode loop (main.py:340-371, benchmark.py:293-338).
+ * begin: h[hidden] = embed[*tok] (tok: device int64, clamped to the vocabulary) and, if rope_row != NULL,
+ *        rope_row[128] = rope_tab[*pos] (rope_tab fp32 [max_seq][cos 64 | sin 64]) for qeft_rope_attn_decode(tab_rows = 1).
+ * end:   if greedy: *tok = argmax(logits[vocab]) (lowest index among equal maxima); always *pos += 1. */
+int qeft_token_begin(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h, void* rope_row,
+                     int hidden, int vocab, int max_seq, qeft_stream_t stream);
+int qeft_token_end(const void* logits, void* tok, int* pos, int vocab, int greedy, qeft_stream_t stream);
 
 #ifdef __cplusplus
 }

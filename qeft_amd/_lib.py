@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqeft_hip.so")
+# QEFT_HIP_LIB: load another build of the same ABI (A/B timing of two builds on one GPU box); never a fallback
+LIB_PATH = os.environ.get("QEFT_HIP_LIB") or os.path.join(_HERE, "lib", "libqeft_hip.so")
 
 _p, _i = ctypes.c_void_p, ctypes.c_int
 
@@ -28,7 +29,10 @@ SIGNATURES = {
     "qeft_gemv_w4_silu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_rmsnorm": [_p, _p, _p, _p, _p, _i, _i, ctypes.c_float, _p],
     "qeft_silu_mul": [_p, _p, _p, _i, _p],
-    "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_attn_workspace_bytes": [_i, _i],
+    "qeft_token_begin": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_token_end": [_p, _p, _p, _i, _i, _p],
+    "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
 }
 
 _lib = None

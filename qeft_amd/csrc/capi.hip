@@ -14,8 +14,13 @@ hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, voi
                           float eps, hipStream_t st);
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
-                                   void* vc, const int* pos, const int* out_pos, void* out, int n_heads, int n_kv,
-                                   int max_seq, hipStream_t st);
+                                   void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
+                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st);
+size_t attn_workspace_bytes(int n_heads, int S);
+hipError_t token_begin_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
+                              void* rope_row, int hidden, int vocab, int max_seq, hipStream_t st);
+hipError_t token_end_launch(const void* logits, void* tok, int* pos, int vocab, int greedy, hipStream_t st);
+extern unsigned long long* g_attn_dbg;
 hipError_t dequant_w4_launch(const void* qw, const void* scales, const void* zeros, const void* ow, void* out, int N,
                              int K, int G, int n_out, hipStream_t st);
 hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream_t st);
@@ -287,14 +292,40 @@ int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_strea
     return finish(qeft::silu_mul_launch(gate, up, out, n, (hipStream_t)stream));
 }
 
+void qeft_debug_attn_stamps(void* p) { qeft::g_attn_dbg = (unsigned long long*)p; }
+
+int qeft_attn_workspace_bytes(int n_heads, int n_split) {
+    if (n_heads < 1 || n_heads > 4096 || n_split < 1 || n_split > 8) return 0;
+    return (int)qeft::attn_workspace_bytes(n_heads, n_split);
+}
+
 int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
-                          void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out, int n_heads,
-                          int n_kv_heads, int max_seq, qeft_stream_t stream) {
-    if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || max_seq < 1 || max_seq > 32768) return QEFT_ERR_SHAPE;
+                          int tab_rows, void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out,
+                          void* workspace, int n_split, int n_heads, int n_kv_heads, int max_seq, qeft_stream_t stream) {
+    if (tab_rows != 1 && tab_rows < max_seq) return QEFT_ERR_SHAPE;
+    if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || max_seq < 16 || max_seq % 16 != 0 || max_seq > 32768)
+        return QEFT_ERR_SHAPE;
+    if (n_split != 1 && n_split != 2 && n_split != 4 && n_split != 8) return QEFT_ERR_SHAPE;
     if (!q || !k || !v || !cos_tab || !sin_tab || !k_cache || !v_cache || !pos || !out) return QEFT_ERR_NULL;
-    if (!aligned16(k_cache) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
-    return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache, v_cache, pos, out_pos, out, n_heads,
-                                                n_kv_heads, max_seq, (hipStream_t)stream));
+    if (n_split > 1 && !workspace) return QEFT_ERR_NULL;
+    if (!aligned16(k_cache) || !aligned16(v_cache) || !aligned16(workspace)) return QEFT_ERR_ALIGN;
+    return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache, v_cache, pos, out_pos, out, workspace,
+                                                n_heads, n_kv_heads, max_seq, n_split, tab_rows, (hipStream_t)stream));
+}
+
+int qeft_token_begin(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h, void* rope_row,
+                     int hidden, int vocab, int max_seq, qeft_stream_t stream) {
+    if (hidden < 8 || hidden % 8 != 0 || vocab < 1 || max_seq < 1) return QEFT_ERR_SHAPE;
+    if (!embed || !tok || !h || (rope_row && (!rope_tab || !pos))) return QEFT_ERR_NULL;
+    if (!aligned16(embed) || !aligned16(h)) return QEFT_ERR_ALIGN;
+    return finish(qeft::token_begin_launch(embed, tok, rope_tab, pos, h, rope_row, hidden, vocab, max_seq, (hipStream_t)stream));
+}
+
+int qeft_token_end(const void* logits, void* tok, int* pos, int vocab, int greedy, qeft_stream_t stream) {
+    if (vocab < 1) return QEFT_ERR_SHAPE;
+    if (!pos || (greedy && (!logits || !tok))) return QEFT_ERR_NULL;
+    if (greedy && !aligned16(logits)) return QEFT_ERR_ALIGN;
+    return finish(qeft::token_end_launch(logits, tok, pos, vocab, greedy, (hipStream_t)stream));
 }
 
 }  // extern "C"

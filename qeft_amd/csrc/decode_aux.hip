@@ -74,160 +74,368 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const f16* __restrict__ g
     h8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float gf = (float)g[j];
-        o[j] = (f16)(gf / (1.f + __expf(-gf)) * (float)u[j]);
+        o[j] = (f16)(silu_f32((float)g[j]) * (float)u[j]);
     }
     *(h8*)(out + i) = o;
 }
 
-// Single-token attention for one sequence.  grid = n_heads, block = 256, head_dim = 128.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// maximum over the 64 lanes of a wave, every lane gets it: 4 DPP steps inside each row of 16, then two cross-row swaps
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int kAttnRec = 132;   // floats per (head, split) record of the workspace: acc[128], max, sum, pad
+
+// Single-token attention for one sequence.  grid = n_heads * S, block = 256 (4 waves), head_dim = 128.
 //   q,k,v  : this token's projections [n_heads*128], [n_kv*128], [n_kv*128] (fp16)
-//   cos/sin: [max_seq][64] fp32 rotary table
+//   cos/sin: [tab_rows][64] fp32 rotary table; tab_rows == 1: the row of THIS position, selected by the caller
 //   kc, vc : caches [n_kv][max_seq][128] fp16;  *pos_ptr = index of this token (0-based)
-//   out    : [n_heads*128] fp16
+//   out    : [n_heads*128] fp16, element i stored at out_pos[i] when out_pos is given
+//   ws     : S > 1 only: [n_heads*S][kAttnRec] floats + [n_heads] uint32 arrival counters (zero before first use)
+// 32 blocks pulling a whole head's K and V each are bound by what ONE CU can load (~100 KB took ~4 us), so a head is
+// split over S blocks and the kernel is organised around latency:
+//   * everything that does not depend on `pos` is requested first -- q/k/v, out_pos and, unconditionally, the K
+//     quarter-rows and V pieces of the first PRE runs of each wave (rows past the context are fetched and ignored);
+//     only the rotary entry waits for `pos`;
+//   * positions are dealt in runs of 16 to the 4*S waves of a head (run r belongs to wave r % (4*S)); each wave
+//     computes its scores, its own maximum, exp and P.V partials with wave-level operations only (flash-decoding
+//     split), the block merges its 4 waves once through LDS;
+//   * S > 1: every block publishes its (acc, max, sum) record with write-through stores and takes a ticket from the
+//     head's counter; the block that draws the last ticket merges the S records in split order (deterministic) and
+//     re-arms the counter.  Nobody waits for anybody (MI355X_MICROARCH.md, inter-workgroup visibility, table row 1).
+template <int PRE>
 __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ v, const float* __restrict__ cs,
                                                                const float* __restrict__ sn, f16* __restrict__ kc,
                                                                f16* __restrict__ vc, const int* __restrict__ pos_ptr,
                                                                const int* __restrict__ out_pos, f16* __restrict__ out,
-                                                               int n_heads, int n_kv, int max_seq) {
+                                                               float* __restrict__ ws, int n_heads, int n_kv,
+                                                               int max_seq, int S, int tab_rows,
+                                                               unsigned long long* dbg) {
     constexpr int HD = 128;
+    unsigned long long stamp[10];
+    auto mark = [&](int i) {
+        if (dbg) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    };
+    unsigned long long rt0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    mark(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
-    float* sc = (float*)smem_raw;            // [max_seq] scores / probabilities
-    float* qs = sc + max_seq;                // [128] rotated, pre-scaled q
-    f16* knew = (f16*)(qs + HD);             // [128]
+    float* prob = (float*)smem_raw;          // [max_seq + 16] raw scores
+    float* part = prob + max_seq + 16;       // [16][128] P.V partials: (wave, position class)
+    float* psum = part + 16 * HD;            // [16] exp sums
+    float* wm = psum + 16;                   // [4] wave maxima
+    f16* knew = (f16*)(wm + 4);              // [128]
     f16* vnew = knew + HD;                   // [128]
-    float* part = (float*)(vnew + HD);       // [16][128] output partials
-    __shared__ float sm[4];
+    f16* qs = vnew + HD;                     // [128] rotated, pre-scaled q (fp16 like the reference's rotated q)
+    __shared__ int last_ticket;
 
-    const int h = blockIdx.x, t = threadIdx.x;
+    const int h = blockIdx.x / S, sp = blockIdx.x % S, t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int gw = sp * 4 + w, NW = 4 * S;   // this wave among the head's waves
     const int grp = n_heads / n_kv, hk = h / grp;
-    const int pos = *pos_ptr, L = pos + 1;
-    if (pos < 0 || pos >= max_seq) return;   // never index the cache / rotary table out of range
     f16* kch = kc + (size_t)hk * max_seq * HD;
     f16* vch = vc + (size_t)hk * max_seq * HD;
+    const bool appender = (sp == 0) && (h % grp == 0);
 
-    // Every cache byte this block needs is known as soon as `pos` is: the K quarter-rows and V pieces of the first 256
-    // positions are requested up front, right behind the token's own q/k/v and rotary entries, so the kernel pays two
-    // dependent memory round trips (pos, then everything) instead of four (pos, q/k/v, K rows, V rows).
-    const int qd = t & 3;
-    const int dg = t & 15, pg = t >> 4;
-    float rc = 0.f, rs = 0.f, ra = 0.f, rb = 0.f;
+    // ---- loads that do not depend on pos.  All of them are unconditional (addresses selected, never branched on)
+    // and nothing is converted here: a conversion or a divergent branch makes the compiler wait for the load on the
+    // spot, which serialises one memory round trip per load group at the top of the kernel.
+    const int ti = t & 127;
+    const int* opp = out_pos ? out_pos + h * HD + ti : pos_ptr;        // dummy in-range address when there is no map
+    const int opos_raw = *opp;
+    const f16* src = (t < 64) ? q + h * HD + t : (t < 128) ? k + hk * HD + (t - 64) : v + hk * HD + (t - 128);
+    const f16 raw_a = src[0];
+    const f16 raw_b = src[(t < 128) ? 64 : 0];
+    float rc = 0.f, rsn = 0.f;
+    if (tab_rows == 1) {                      // the caller already selected this position's rotary row: no wait for pos
+        rc = cs[t & 63];
+        rsn = sn[t & 63];
+    }
+    // `pos` is a scalar load: it arrives while the vector loads above are in flight, and nothing above waits for it
+    mark(1);
+    const int pos = *pos_ptr, L = pos + 1;
+    if (pos < 0 || pos >= max_seq) return;   // never index the cache / rotary table out of range (grid-uniform)
+    if (dbg) { asm volatile("" :: "s"(pos)); }
+    mark(2);
+    // ---- K/V of the first PRE runs of this wave.  One CU pulls ~50 GB/s, so only rows inside the context are
+    // fetched; the load COUNT stays fixed (runs past the context re-read row 0, an L1 hit), which keeps the compiler's
+    // vmcnt bookkeeping exact and lets the rotary / scores start while later rows are still in flight.
+    // score role: position pj of the run, dims qd*8 + 32*j .. +8 (j = 0..3): the 4 lanes of a position read 64
+    // contiguous bytes per load instruction
+    const int qd = lane & 3, pj = lane >> 2;
+    const int dg = lane & 15, pc = lane >> 4;    // P.V role: dims dg*8.., positions pc*4 .. pc*4+3 of the run
+    h8 kpre[PRE][4], vpre[PRE][4];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        const int r0 = (i * NW + gw) * 16;                      // max_seq % 16 == 0: a run never straddles the cache end
+        const int krow = r0 < L ? r0 + pj : 0;
+        const h8* row = (const h8*)(kch + (size_t)krow * HD + qd * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kpre[i][j] = row[j * 4];
+    }
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+        const int r0 = (i * NW + gw) * 16;
+        const int vrow = r0 < L ? r0 + pc * 4 : 0;
+        const h8* row = (const h8*)(vch + (size_t)vrow * HD + dg * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vpre[i][j] = row[j * (HD / 8)];
+    }
+    const int opos = out_pos ? opos_raw : h * HD + ti;
+    const float ra = (float)raw_a, rb = (float)raw_b;
     if (t < 128) {
         const int i = t & 63;
-        rc = cs[(size_t)pos * 64 + i];
-        rs = sn[(size_t)pos * 64 + i];
-        const f16* src = (t < 64) ? q + h * HD : k + hk * HD;
-        ra = (float)src[i];
-        rb = (float)src[i + 64];
-    } else {
-        ra = (float)v[hk * HD + (t - 128)];
-    }
-    constexpr int KPRE = 4, VPRE = 16;          // 4 passes x 64 positions; 16 x 16 positions
-    h8 kpre[KPRE][4], vpre[VPRE];
-#pragma unroll
-    for (int i = 0; i < KPRE; ++i)
-        if (i * 64 < L) {                       // block-uniform
-            const h8* row = (const h8*)(kch + (size_t)min(i * 64 + (t >> 2), max_seq - 1) * HD + qd * 32);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) kpre[i][j] = row[j];
-        }
-#pragma unroll
-    for (int i = 0; i < VPRE; ++i)
-        if (i * 16 < L) vpre[i] = *(const h8*)(vch + (size_t)min(pg + 16 * i, max_seq - 1) * HD + dg * 8);
-
-    if (t < 64) {
-        const float scale = 0.08838834764831845f;  // 1/sqrt(128)
-        qs[t] = (ra * rc - rb * rs) * scale;
-        qs[t + 64] = (rb * rc + ra * rs) * scale;
-    } else if (t < 128) {
-        const int i = t - 64;
-        const f16 k0 = (f16)(ra * rc - rb * rs), k1 = (f16)(rb * rc + ra * rs);
-        knew[i] = k0;
-        knew[i + 64] = k1;
-        if (h % grp == 0) {
-            kch[(size_t)pos * HD + i] = k0;
-            kch[(size_t)pos * HD + i + 64] = k1;
+        const float c = (tab_rows == 1) ? rc : cs[(size_t)pos * 64 + i];
+        const float sv = (tab_rows == 1) ? rsn : sn[(size_t)pos * 64 + i];
+        const float r0 = ra * c - rb * sv, r1 = rb * c + ra * sv;
+        if (t < 64) {
+            const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+            qs[i] = (f16)(r0 * scale);
+            qs[i + 64] = (f16)(r1 * scale);
+        } else {
+            const f16 k0 = (f16)r0, k1 = (f16)r1;
+            knew[i] = k0;
+            knew[i + 64] = k1;
+            if (appender) {
+                kch[(size_t)pos * HD + i] = k0;
+                kch[(size_t)pos * HD + i + 64] = k1;
+            }
         }
     } else {
         const int i = t - 128;
         const f16 vv = (f16)ra;
         vnew[i] = vv;
-        if (h % grp == 0) vch[(size_t)pos * HD + i] = vv;
+        if (appender) vch[(size_t)pos * HD + i] = vv;
     }
-    __syncthreads();
+    // workgroup barrier for LDS only: __syncthreads() would also drain the K/V prefetch that is still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    mark(3);
 
-    // scores: 4 lanes per position (32 dims each, q quarter kept in registers), 64 positions per pass
-    float qreg[32];
+    // ---- scores of this wave's runs: raw score -> prob[], running maximum
+    h2 qreg[16];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) qreg[j] = qs[qd * 32 + j];
+    for (int j = 0; j < 16; ++j) qreg[j] = *(const h2*)(qs + (j >> 2) * 32 + qd * 8 + 2 * (j & 3));
     float lmax = -3.0e38f;
-    auto score_pass = [&](int p0, const h8* kr) {
-        const int p = p0 + (t >> 2);
-        float s = 0.f;
-        if (p < L) {
-            if (p == pos) {
+    auto score_run = [&](int i, const h8* kr) {
+        const int p = (i * NW + gw) * 16 + pj;
+        float sdot = 0.f;
+        // v_dot2_f32_f16: two products per instruction, fp32 accumulation, no conversions
+        if (p == pos) {
 #pragma unroll
-                for (int j = 0; j < 32; ++j) s += qreg[j] * (float)knew[qd * 32 + j];
-            } else {
+            for (int j = 0; j < 16; ++j) sdot = dot2(qreg[j], *(const h2*)(knew + (j >> 2) * 32 + qd * 8 + 2 * (j & 3)), sdot);
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 kw = __builtin_bit_cast(u32x4, kr[j]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s += qreg[j * 8 + e] * (float)kr[j][e];
-                }
+                for (int e = 0; e < 4; ++e) sdot = dot2(qreg[j * 4 + e], as_h2(kw[e]), sdot);
             }
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (p < L) {
-            if (qd == 0) sc[p] = s;
-            lmax = fmaxf(lmax, s);
-        }
+        sdot += dpp_mov<0xB1>(sdot);
+        sdot += dpp_mov<0x4E>(sdot);
+        if (p >= L) sdot = -3.0e38f;         // fetched but outside the context (possibly uninitialised cache rows)
+        if (qd == 0) prob[p] = sdot;
+        lmax = fmaxf(lmax, sdot);
     };
 #pragma unroll
-    for (int i = 0; i < KPRE; ++i)
-        if (i * 64 < L) score_pass(i * 64, kpre[i]);
-    for (int p0 = KPRE * 64; p0 < L; p0 += 64) {
+    for (int i = 0; i < PRE; ++i)
+        if ((i * NW + gw) * 16 < L) score_run(i, kpre[i]);
+    for (int i = PRE; (i * NW + gw) * 16 < L; ++i) {
         h8 kr[4];
-        const h8* row = (const h8*)(kch + (size_t)min(p0 + (t >> 2), max_seq - 1) * HD + qd * 32);
+        const h8* row = (const h8*)(kch + (size_t)((i * NW + gw) * 16 + pj) * HD + qd * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) kr[j] = row[j];
-        score_pass(p0, kr);
+        for (int j = 0; j < 4; ++j) kr[j] = row[j * 4];
+        score_run(i, kr);
     }
-    const float mx = block_max_256(lmax, sm);
-    float lsum = 0.f;
-    for (int p = t; p < L; p += 256) {
-        const float e = __expf(sc[p] - mx);
-        sc[p] = e;
-        lsum += e;
-    }
-    const float inv = 1.f / block_sum_256(lsum, sm);
-    __syncthreads();
+    const float mw = wave_max(lmax);
+    mark(4);
+    __builtin_amdgcn_wave_barrier();         // prob[] of this wave's runs is written and read by this wave only
 
-    // P.V: thread = (8-dim group, 1 of 16 position classes); 16-byte V pieces; partials combined through LDS
+    // ---- P.V partials of this wave's runs
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    auto pv = [&](int p, h8 vv) {
-        if (p == pos) vv = *(const h8*)(vnew + dg * 8);
-        const float w = sc[p];
+    float lsum = 0.f;
+    auto pv_run = [&](int i, const h8* vr) {
+        const int p0 = (i * NW + gw) * 16 + pc * 4;
+        const f32x4 sraw = *(const f32x4*)(prob + p0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += w * (float)vv[e];
+        for (int j = 0; j < 4; ++j) {
+            const int p = p0 + j;
+            if (p < L) {
+                const float e = __expf(sraw[j] - mw);
+                h8 vv = vr[j];
+                if (p == pos) vv = *(const h8*)(vnew + dg * 8);
+                lsum += e;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o[d] += e * (float)vv[d];
+            }
+        }
     };
 #pragma unroll
-    for (int i = 0; i < VPRE; ++i)
-        if (pg + 16 * i < L) pv(pg + 16 * i, vpre[i]);
-    for (int p = pg + 16 * VPRE; p < L; p += 16) pv(p, *(const h8*)(vch + (size_t)p * HD + dg * 8));
+    for (int i = 0; i < PRE; ++i)
+        if ((i * NW + gw) * 16 < L) pv_run(i, vpre[i]);
+    for (int i = PRE; (i * NW + gw) * 16 < L; ++i) {
+        h8 vr[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[pg * HD + dg * 8 + e] = o[e];
-    __syncthreads();
-    if (t < HD) {
-        float acc = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc += part[g * HD + t];
-        const int oi = h * HD + t;
-        out[out_pos ? out_pos[oi] : oi] = (f16)(acc * inv);
+        for (int j = 0; j < 4; ++j)
+            vr[j] = *(const h8*)(vch + (size_t)((i * NW + gw) * 16 + pc * 4 + j) * HD + dg * 8);
+        pv_run(i, vr);
     }
+    {
+        float* dst = part + (w * 4 + pc) * HD + dg * 8;
+        *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
+        *(f32x4*)(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+        if (dg == 0) psum[w * 4 + pc] = lsum;
+        if (lane == 0) wm[w] = mw;
+    }
+    mark(5);
+    __syncthreads();
+    mark(6);
+    // ---- merge the block's 4 waves (a wave without positions has max -3e38: factor 0)
+    const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    float acc = 0.f, den = 0.f;
+    if (t < HD) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float f = __expf(wm[g >> 2] - M);
+            acc += f * part[g * HD + t];
+            den += f * psum[g];
+        }
+    }
+    if (S == 1) {
+        if (t < HD) out[opos] = (f16)(acc / den);
+        if (dbg && lane == 0) {
+            mark(7);
+            unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + w) * 12;
+            d[0] = rt0; d[1] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 8; ++i) d[2 + i] = stamp[i];
+            d[10] = d[11] = 0;
+        }
+        return;
+    }
+    // ---- publish this split's record, take a ticket; the last arriver merges the head
+    float* rec = ws + (size_t)(h * S + sp) * kAttnRec;
+    if (t < HD) st_agent(rec + t, acc);
+    if (t == 0) {
+        st_agent(rec + HD, M);
+        st_agent(rec + HD + 1, den);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    mark(7);
+    unsigned* ctr = (unsigned*)(ws + (size_t)n_heads * S * kAttnRec) + h;
+    if (t == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_ticket = (ticket == (unsigned)(S - 1));
+        if (ticket == (unsigned)(S - 1)) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    mark(8);
+    if (dbg && lane == 0 && !last_ticket) {
+        unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + w) * 12;
+        d[0] = rt0; d[1] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 9; ++i) d[2 + i] = stamp[i];
+        d[11] = 0;
+    }
+    if (!last_ticket) return;
+    if (t < HD) {
+        const float* r0 = ws + (size_t)h * S * kAttnRec;
+        float Mh = -3.0e38f;
+        for (int j = 0; j < S; ++j) Mh = fmaxf(Mh, ld_agent(r0 + j * kAttnRec + HD));
+        float a2 = 0.f, d2 = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float f = __expf(ld_agent(r0 + j * kAttnRec + HD) - Mh);   // a split without positions: factor 0
+            a2 += f * ld_agent(r0 + j * kAttnRec + t);
+            d2 += f * ld_agent(r0 + j * kAttnRec + HD + 1);
+        }
+        out[opos] = (f16)(a2 / d2);
+    }
+    if (dbg && lane == 0) {
+        mark(9);
+        unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + w) * 12;
+        d[0] = rt0; d[1] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < 9; ++i) d[2 + i] = stamp[i];
+        d[11] = stamp[9];
+    }
+}
+
+// ---- token boundary of the decode loop (main.py:340-371 / benchmark.py:293-338: embedding lookup in front of the
+// layers, greedy argmax behind lm_head).  Two small launches instead of four framework kernels per token.
+// begin: h = embed[tok], rope_row = rope_tab[pos] (cos 64 | sin 64).  grid = hidden / 2048 (+1), block 256.
+__global__ __launch_bounds__(256) void token_begin_kernel(const f16* __restrict__ embed, const long long* __restrict__ tok,
+                                                          const float* __restrict__ rope_tab, const int* __restrict__ pos,
+                                                          f16* __restrict__ h, float* __restrict__ rope_row, int hidden,
+                                                          int vocab, int max_seq) {
+    const long long tk = min(max(*tok, 0ll), (long long)vocab - 1);
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i < hidden) *(h8*)(h + i) = *(const h8*)(embed + (size_t)tk * hidden + i);
+    if (blockIdx.x == 0 && threadIdx.x < 128 && rope_row) {
+        const int p = min(max(*pos, 0), max_seq - 1);
+        rope_row[threadIdx.x] = rope_tab[(size_t)p * 128 + threadIdx.x];
+    }
+}
+
+// end: tok = argmax(logits) when greedy (lowest index among equal maxima, like torch.argmax), pos += 1.  One block.
+__global__ __launch_bounds__(1024) void token_end_kernel(const f16* __restrict__ logits, long long* __restrict__ tok,
+                                                         int* __restrict__ pos, int vocab, int greedy) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int t = threadIdx.x;
+    if (greedy) {
+        float best = -INFINITY;
+        int idx = 0x7fffffff;
+        for (int i = t * 8; i < vocab; i += 1024 * 8) {
+            if (i + 8 <= vocab) {
+                const h8 v = *(const h8*)(logits + i);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if ((float)v[j] > best) { best = (float)v[j]; idx = i + j; }
+            } else {
+                for (int j = i; j < vocab; ++j)
+                    if ((float)logits[j] > best) { best = (float)logits[j]; idx = j; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(idx, o);
+            if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+        }
+        if ((t & 63) == 0) { bv[t >> 6] = best; bi[t >> 6] = idx; }
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < 16; ++w)
+                if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+            *tok = idx == 0x7fffffff ? 0 : idx;
+        }
+    }
+    if (t == 0) *pos = *pos + 1;
+}
+
+hipError_t token_begin_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
+                              void* rope_row, int hidden, int vocab, int max_seq, hipStream_t st) {
+    hipLaunchKernelGGL(token_begin_kernel, dim3((hidden / 8 + 255) / 256), dim3(256), 0, st, (const f16*)embed,
+                       (const long long*)tok, (const float*)rope_tab, pos, (f16*)h, (float*)rope_row, hidden, vocab, max_seq);
+    return hipGetLastError();
+}
+
+hipError_t token_end_launch(const void* logits, void* tok, int* pos, int vocab, int greedy, hipStream_t st) {
+    hipLaunchKernelGGL(token_end_kernel, dim3(1), dim3(1024), 0, st, (const f16*)logits, (long long*)tok, pos, vocab, greedy);
+    return hipGetLastError();
 }
 
 hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int H,
@@ -243,19 +451,27 @@ hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, h
     return hipGetLastError();
 }
 
+unsigned long long* g_attn_dbg = nullptr;   // lab only: per-wave phase stamps
+size_t attn_workspace_bytes(int n_heads, int S) { return S > 1 ? ((size_t)n_heads * S * kAttnRec + n_heads) * 4 : 0; }
+
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
-                                   void* vc, const int* pos, const int* out_pos, void* out, int n_heads, int n_kv,
-                                   int max_seq, hipStream_t st) {
-    const size_t smem = (size_t)max_seq * 4 + 128 * 4 + 2 * 128 * 2 + 16 * 128 * 4;
-    if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)rope_attn_decode_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(rope_attn_decode_kernel, dim3(n_heads), dim3(256), smem, st, (const f16*)q, (const f16*)k,
-                       (const f16*)v, (const float*)cs, (const float*)sn, (f16*)kc, (f16*)vc, pos, out_pos, (f16*)out,
-                       n_heads, n_kv, max_seq);
-    return hipGetLastError();
+                                   void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
+                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st) {
+    const size_t smem = (size_t)(max_seq + 16) * 4 + 16 * 128 * 4 + 16 * 4 + 4 * 4 + 3 * 128 * 2;
+    // prefetch 256 positions per head whatever the split: PRE runs of 16 on each of the 4*S waves
+    auto launch = [&](auto kern) -> hipError_t {
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_heads * S), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v,
+                           (const float*)cs, (const float*)sn, (f16*)kc, (f16*)vc, pos, out_pos, (f16*)out, (float*)ws,
+                           n_heads, n_kv, max_seq, S, tab_rows, g_attn_dbg);
+        return hipGetLastError();
+    };
+    if (S == 1) return launch(rope_attn_decode_kernel<4>);
+    if (S == 2) return launch(rope_attn_decode_kernel<2>);
+    return launch(rope_attn_decode_kernel<1>);
 }
 
 }  // namespace qeft

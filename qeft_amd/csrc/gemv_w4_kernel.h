@@ -156,7 +156,7 @@ __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
             for (int j = 0; j < 4; ++j) {
                 const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
                 const float g0 = (float)t[0], g1 = (float)t[1];
-                xst[p][j] = as_u32(h2{(f16)(g0 / (1.f + __expf(-g0)) * (float)u[0]), (f16)(g1 / (1.f + __expf(-g1)) * (float)u[1])});
+                xst[p][j] = as_u32(h2{(f16)(silu_f32(g0) * (float)u[0]), (f16)(silu_f32(g1) * (float)u[1])});
             }
         }
     }

@@ -86,6 +86,10 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     mark(0);
 
     // ---- 1. oldest loads: x, the transform operand, the outlier slab, the scales
+    // Every load here is UNCONDITIONAL with a clamped / substituted address and nothing consumes a loaded value before
+    // the weight ring has been issued: a load inside a branch (even a block-uniform one) ends in register copies at
+    // the join, for which the compiler waits on the spot -- one exposed memory round trip in front of the weight
+    // stream.  Passes beyond the data re-read the last vector (an L1 hit).
     const int xtotal = MR * a.K;
     const int xvecs = xtotal / 8;
     u32x4 xst[XG ? 1 : 4];
@@ -95,33 +99,30 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     if (!XG) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            if (p == 0 || p * kBlock < xvecs) {           // block-uniform: passes beyond the row are not loaded at all
-                const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
-                xst[p] = *(const u32x4*)(a.x + e);
-                if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
-            }
+            const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
+            xst[p] = *(const u32x4*)(a.x + e);
+            if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
         }
     }
     const int slab_vecs = OUTL ? RS * 8 * (2 * a.n_out) / 8 : 0;      // 8 interleaved rows of 2*n_out halves per row set
-    const f16* osrc = (OUTL && !a.ow_plain) ? a.ow_il + (size_t)(rg0 >> 1) * 4 * (2 * a.n_out) : nullptr;
-    u32x4 ost[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    if (OUTL && !a.ow_plain) {
+    const bool slab_il = OUTL && !a.ow_plain;
+    const f16* osrc = slab_il ? a.ow_il + (size_t)(rg0 >> 1) * 4 * (2 * a.n_out) : a.x;
+    u32x4 ost[2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            if (p == 0 || p * kBlock < slab_vecs) ost[p] = *(const u32x4*)(osrc + (size_t)min(p * kBlock + tid, slab_vecs - 1) * 8);
-    }
+    for (int p = 0; p < 2; ++p)
+        ost[p] = *(const u32x4*)(osrc + (size_t)(slab_il ? min(p * kBlock + tid, slab_vecs - 1) : 0) * 8);
     const int ngroups = per_channel ? 1 : nsteps;
     const int szn = ngroups * 8 * RS;                                  // dword pairs of two adjacent rows
     uint32_t sst[2], zst[2];
-    u32x4 szv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    u32x4 szv[2];
     const int szvecs = RS * ngroups * 4;                               // 16-byte pieces of the block's shadow scales
-    const uint32_t* szsrc = a.sz_blk ? a.sz_blk + (size_t)set0 * ngroups * 16 : nullptr;
-    if (a.sz_blk) {
-        // contiguous [RS][K/G][16] dwords for this block: coalesced 16-byte loads
+    const bool shadow = a.sz_blk != nullptr;
+    const uint32_t* szsrc = shadow ? a.sz_blk + (size_t)set0 * ngroups * 16 : (const uint32_t*)a.x;
+    // contiguous [RS][K/G][16] dwords for this block: coalesced 16-byte loads
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            if (p == 0 || p * kBlock < szvecs) szv[p] = *(const u32x4*)(szsrc + (size_t)min(p * kBlock + tid, szvecs - 1) * 4);
-    } else {
+    for (int p = 0; p < 2; ++p)
+        szv[p] = *(const u32x4*)(szsrc + (size_t)(shadow ? min(p * kBlock + tid, szvecs - 1) : 0) * 4);
+    if (!shadow) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int i = min(p * kBlock + tid, szn - 1);
@@ -155,14 +156,15 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     if (XT == 1) {
         float ss = 0.f;
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            if (p * kBlock + tid < xvecs) {
+        for (int p = 0; p < 4; ++p) {
+            float sp = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const h2 t = as_h2(xst[p][j]);
-                    ss += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
-                }
+            for (int j = 0; j < 4; ++j) {
+                const h2 t = as_h2(xst[p][j]);
+                sp += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
             }
+            ss += (p * kBlock + tid < xvecs) ? sp : 0.f;   // passes beyond the row re-read the last vector
+        }
         mark(6);
         ss = row16_sum(ss);
         ss += __shfl_xor(ss, 16);
@@ -175,7 +177,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         const float rs = rsqrtf(tot / (float)a.K + a.xt_eps);
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            if (p == 0 || p * kBlock < xvecs) {
+            if (p == 0 || p * kBlock < xvecs) {            // block-uniform, registers only
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const h2 t = as_h2(xst[p][j]), gm = as_h2(ast[p][j]);
@@ -189,8 +191,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
-                    const float g0 = (float)t[0], g1 = (float)t[1];
-                    xst[p][j] = as_u32(h2{(f16)(g0 / (1.f + __expf(-g0)) * (float)u[0]), (f16)(g1 / (1.f + __expf(-g1)) * (float)u[1])});
+                    xst[p][j] = as_u32(h2{(f16)(silu_f32((float)t[0]) * (float)u[0]), (f16)(silu_f32((float)t[1]) * (float)u[1])});
                 }
             }
     }

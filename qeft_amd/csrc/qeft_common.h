@@ -87,4 +87,8 @@ struct GemvGroupArgs {
 
 __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 
+// silu(g) = g / (1 + e^-g) in fp32 with the hardware reciprocal (1 ulp) instead of an IEEE division: the result is
+// rounded to fp16 right after, and a division costs ~10 VALU instructions in a prologue every block repeats.
+__device__ __forceinline__ float silu_f32(float g) { return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
+
 }  // namespace qeft

@@ -13,6 +13,7 @@ C-ABI launches on static buffers so the whole step can be captured into one hipG
 used by the tests and by `eval_nll` as the parity target ("PPL vs reference" on synthetic weights).
 """
 import ctypes
+import os
 import math
 from dataclasses import dataclass
 
@@ -239,6 +240,13 @@ class DecodeEngine:
         self.logits = torch.zeros(1, s.vocab, **f16)
         self.kc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
         self.vc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
+        # a head's context can be dealt over attn_split blocks; at the contexts benchmarked (<= 512) the merge hand-off
+        # costs more than the split saves, so the default is one block per head
+        self.rope_tab = torch.cat([model.rope_cos, model.rope_sin], 1).contiguous()   # [max_seq][cos 64 | sin 64]
+        self.rope_row = torch.zeros(1, 128, dtype=torch.float32, device=dev)
+        self.attn_split = int(os.environ.get("QEFT_ATTN_SPLIT", "1"))
+        nws = self.lib.qeft_attn_workspace_bytes(s.n_heads, self.attn_split)
+        self.attn_ws = torch.zeros(nws // 4, dtype=torch.float32, device=dev) if nws else None
         self.greedy = False
         self.graph = None
         self.use_graph = use_graph
@@ -303,7 +311,11 @@ class DecodeEngine:
         st = torch.cuda.current_stream(self.dev).cuda_stream
         h, h2 = self.hbuf
         if not linears_only:
-            torch.index_select(self.m.model.embed_tokens.weight, 0, self.tok, out=h.view(1, -1))
+            # h = embed[tok] and this position's rotary row, selected once per token (no attention launch waits for
+            # pos before its rotary)
+            ck(lib.qeft_token_begin(self.m.model.embed_tokens.weight.data_ptr(), self.tok.data_ptr(),
+                                    self.rope_tab.data_ptr(), self.pos.data_ptr(), h.data_ptr(), self.rope_row.data_ptr(),
+                                    s.hidden, s.vocab, s.max_seq, st))
         g, no = s.group_size, s.n_out
         r0 = self.rank * self.hs
         for li, L in enumerate(self.m.model.layers):
@@ -319,10 +331,11 @@ class DecodeEngine:
                 self.v.view(P, self.kvs).copy_(self.qkv_all[:, self.hs + self.kvs:])
             if not linears_only:
                 ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
-                                             self.m.rope_cos.data_ptr(), self.m.rope_sin.data_ptr(),
+                                             self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
                                              self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
                                              self.att_pos[li].data_ptr() if self.att_pos[li] is not None else None,
-                                             self.att.data_ptr(), s.n_heads, s.n_kv_heads, s.max_seq, st))
+                                             self.att.data_ptr(), self.attn_ws.data_ptr() if self.attn_ws is not None else None,
+                                             self.attn_split, s.n_heads, s.n_kv_heads, s.max_seq, st))
             o = lin["o"]
             ids = None   # the attention kernel already stored its output in o_proj's column order
             ow_o = o.oweight_interleaved.data_ptr() if no else None
@@ -367,9 +380,8 @@ class DecodeEngine:
         ck(lib.qeft_rmsnorm(h.data_ptr(), None, self.m.model.norm.data_ptr(), None, self.hn.data_ptr(), 1,
                             s.hidden, s.rms_eps, st))
         torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
-        if self.greedy:
-            torch.argmax(self.logits, dim=-1, out=self.tok)
-        self.pos.add_(1)
+        ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
+                              1 if self.greedy else 0, st))
 
     def capture(self, linears_only=False):
         """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires)."""

@@ -49,9 +49,13 @@ def test_silu_mul_vs_torch_fp32():
     assert torch.allclose(o.float(), ref, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("n_heads,n_kv,steps", [(4, 4, 70), (8, 2, 300)])
-def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps):
+@pytest.mark.parametrize("n_heads,n_kv,steps,split", [(4, 4, 70, 1), (8, 2, 300, 1), (32, 32, 200, 4), (8, 2, 300, 2),
+                                                       (32, 8, 330, 8), (4, 4, 40, 4)])
+def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps, split):
     from qeft_amd import _lib
+    nws = _lib.lib().qeft_attn_workspace_bytes(n_heads, split)
+    assert (nws > 0) == (split > 1)
+    ws = torch.zeros(max(nws // 4, 4), dtype=torch.float32, device=DEV)
     torch.manual_seed(2)
     hd, max_seq = 128, 512
     inv = 1.0 / (10000.0 ** (torch.arange(0, 64, dtype=torch.float64) / 64))
@@ -72,10 +76,15 @@ def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps):
     kr = torch.stack([rope(K[t], t) for t in range(steps)]).half().float()   # cache holds fp16
     for t in range(steps):
         pos.fill_(t)
-        _lib.check(_lib.lib().qeft_rope_attn_decode(Q[t].data_ptr(), K[t].data_ptr(), V[t].data_ptr(), cs.data_ptr(),
-                                                    sn.data_ptr(), kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
-                                                    None, out.data_ptr(), n_heads, n_kv, max_seq, _st()))
-        if t in (0, 1, steps // 2, steps - 1):
+        # odd steps hand over the pre-selected rotary row (tab_rows = 1), even steps the whole table
+        row = t % 2 == 1
+        _lib.check(_lib.lib().qeft_rope_attn_decode(Q[t].data_ptr(), K[t].data_ptr(), V[t].data_ptr(),
+                                                    cs[t].data_ptr() if row else cs.data_ptr(),
+                                                    sn[t].data_ptr() if row else sn.data_ptr(), 1 if row else max_seq,
+                                                    kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
+                                                    None, out.data_ptr(), ws.data_ptr(), split, n_heads, n_kv, max_seq,
+                                                    _st()))
+        if t in (0, 1, steps // 2, steps - 1) or (split > 1 and t % 7 == 3):
             q = rope(Q[t], t)                                                  # [H, 128]
             rep = n_heads // n_kv
             kk = kr[:t + 1].repeat_interleave(rep, 1)                          # [L, H, 128]
@@ -84,16 +93,27 @@ def test_rope_attention_decode_vs_torch_fp32(n_heads, n_kv, steps):
             ref = torch.einsum("hl,lhd->hd", att.softmax(-1), vv).reshape(-1)
             torch.cuda.synchronize()
             assert torch.allclose(out.float(), ref, rtol=5e-3, atol=5e-3), t
-    assert torch.allclose(kc[:, :steps].float().transpose(0, 1), kr, atol=1e-3)
+    assert torch.allclose(kc[:, :steps].float().transpose(0, 1), kr, rtol=2e-3, atol=1e-3)   # 1 fp16 ulp (fma vs mul+sub)
     # out_pos: the same output, scattered (used to pre-apply o_proj's column order)
     perm = torch.randperm(n_heads * hd, device=DEV).to(torch.int32)
     out2 = torch.empty_like(out)
     pos.fill_(steps - 1)
     _lib.check(_lib.lib().qeft_rope_attn_decode(Q[-1].data_ptr(), K[-1].data_ptr(), V[-1].data_ptr(), cs.data_ptr(),
-                                                sn.data_ptr(), kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
-                                                perm.data_ptr(), out2.data_ptr(), n_heads, n_kv, max_seq, _st()))
+                                                sn.data_ptr(), max_seq, kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
+                                                perm.data_ptr(), out2.data_ptr(), ws.data_ptr(), split, n_heads, n_kv,
+                                                max_seq, _st()))
     torch.cuda.synchronize()
     assert torch.equal(out2[perm.long()], out)
+    # the split merge is order-fixed: repeated launches (back to back, no host sync) give the same bits
+    outs = [torch.empty_like(out) for _ in range(20)]
+    for o in outs:
+        _lib.check(_lib.lib().qeft_rope_attn_decode(Q[-1].data_ptr(), K[-1].data_ptr(), V[-1].data_ptr(), cs.data_ptr(),
+                                                    sn.data_ptr(), max_seq, kc.data_ptr(), vc.data_ptr(), pos.data_ptr(),
+                                                    None, o.data_ptr(), ws.data_ptr(), split, n_heads, n_kv, max_seq,
+                                                    _st()))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, out)
 
 
 @pytest.mark.parametrize("ns,k,r", [((4096, 4096, 4096), 4096, 128), ((11008, 11008), 4096, 128), ((256, 64, 64), 512, 0),
@@ -239,3 +259,36 @@ def test_pack_scales_shadow_layout_and_equivalence(n, k, g):
                                    None, 2, n, k, g, szp)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("vocab,hidden", [(32000, 4096), (1003, 256)])
+def test_token_begin_end_match_torch(vocab, hidden):
+    """Embedding lookup + rotary-row select in front of the layers, greedy argmax + pos += 1 behind lm_head."""
+    from qeft_amd import _lib
+    lib = _lib.lib()
+    torch.manual_seed(5)
+    max_seq = 64
+    embed = torch.randn(vocab, hidden, device=DEV).half()
+    tab = torch.randn(max_seq, 128, device=DEV)
+    tok = torch.tensor([vocab - 3], dtype=torch.long, device=DEV)
+    pos = torch.tensor([17], dtype=torch.int32, device=DEV)
+    h = torch.zeros(hidden, device=DEV, dtype=torch.float16)
+    row = torch.zeros(128, device=DEV)
+    _lib.check(lib.qeft_token_begin(embed.data_ptr(), tok.data_ptr(), tab.data_ptr(), pos.data_ptr(), h.data_ptr(),
+                                    row.data_ptr(), hidden, vocab, max_seq, _st()))
+    torch.cuda.synchronize()
+    assert torch.equal(h, embed[vocab - 3]) and torch.equal(row, tab[17])
+    for trial in range(4):
+        logits = torch.randn(vocab, device=DEV).half()
+        if trial == 1:       # ties: the lowest index wins, like torch.argmax
+            logits[[5, 700, vocab - 1]] = 9.0
+        if trial == 2:
+            logits[vocab - 1] = 11.0
+        _lib.check(lib.qeft_token_end(logits.data_ptr(), tok.data_ptr(), pos.data_ptr(), vocab, 1, _st()))
+        torch.cuda.synchronize()
+        assert int(tok.item()) == int(torch.argmax(logits.float()).item()), trial
+        assert int(pos.item()) == 18 + trial
+    before = int(tok.item())
+    _lib.check(lib.qeft_token_end(None, None, pos.data_ptr(), vocab, 0, _st()))    # not greedy: only the position moves
+    torch.cuda.synchronize()
+    assert int(tok.item()) == before and int(pos.item()) == 22
