@@ -169,7 +169,11 @@ hipError_t gemv_w4_smallm_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
     return hipSuccess;
 }
 
-static int mfma_depth(int K) { return K > 6144 ? 6 : 4; }
+static int mfma_depth(int K) {
+    static const char* env = getenv("QEFT_GEMV_DEPTH");   // lab: force 4 or 6
+    if (env) return atoi(env) == 6 ? 6 : 4;
+    return K > 6144 ? 6 : 4;
+}
 
 // Row-groups per wave-load: 4 (16 rows per block) when that still gives >= 1 block per CU, fewer for small
 // (e.g. row-sharded) layers so they still cover the 256 CUs.  The staged activations must fit the 160 KB LDS:

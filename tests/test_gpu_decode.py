@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import qeft_oracle as O
-from util import REL_TOL, layer_to_torch, rel_err
+from util import REL_TOL, elem_err_ok, layer_to_torch, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -189,10 +189,12 @@ def _arr(ts):
 
 @pytest.mark.parametrize("ns,k", [((4096, 4096, 4096), 4096), ((11008, 11008), 4096), ((256, 256), 512)])
 def test_fused_rmsnorm_group_equals_unfused(ns, k):
-    """RMSNorm folded into the grouped GEMV's x staging == qeft_rmsnorm followed by the grouped GEMV, bit for bit."""
+    """RMSNorm folded into the grouped GEMV == qeft_rmsnorm followed by the grouped GEMV (within the path's tolerance),
+    and both within it of the float64 result on the oracle-dequantised weights."""
     from qeft_amd import _lib
     lib, r, g = _lib.lib(), 128, 128
-    layers = [layer_to_torch(O.make_layer(n, k, r, g, seed=20 + i), DEV) for i, n in enumerate(ns)]
+    bufs = [O.make_layer(n, k, r, g, seed=20 + i) for i, n in enumerate(ns)]
+    layers = [layer_to_torch(b, DEV) for b in bufs]
     torch.manual_seed(5)
     x = (torch.randn(1, k, device=DEV) * 2).half()
     gamma = (1 + 0.1 * torch.randn(k, device=DEV)).half()
@@ -210,8 +212,16 @@ def test_fused_rmsnorm_group_equals_unfused(ns, k):
     _lib.check(lib.qeft_gemv_w4_group(x.data_ptr(), gamma.data_ptr(), 1e-5, len(ns), *packs, None, _arr(szp), _arr(y1),
                                       nn_, k, g, r, _st()))
     torch.cuda.synchronize()
-    for a, b in zip(y0, y1):
-        assert torch.equal(a, b)
+    # the fused kernel stages x * gamma and applies 1/rms to the finished dot products: one fp16 rounding per
+    # activation like the unfused norm, but not the same one -- equal within the path's tolerance, not bit for bit
+    x64 = x.cpu().numpy().astype(np.float64)[0]
+    xn64 = x64 / np.sqrt((x64 ** 2).mean() + 1e-5) * gamma.cpu().numpy().astype(np.float64)
+    for a, b, bf in zip(y0, y1, bufs):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < REL_TOL
+        assert elem_err_ok(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-3, atol_scale=2e-3)
+        w = O.dequant_dense(bf["qweight"], bf["scales"], bf["scaled_zeros"], bf["oweight"], g).astype(np.float64)
+        ref = w @ xn64
+        assert rel_err(a.cpu().numpy()[0], ref) < REL_TOL and rel_err(b.cpu().numpy()[0], ref) < REL_TOL
 
 
 @pytest.mark.parametrize("n,k", [(4096, 11008), (256, 512)])

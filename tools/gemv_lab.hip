@@ -26,20 +26,6 @@ __global__ __launch_bounds__(256) void stream_read(const u32x4* __restrict__ p, 
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[threadIdx.x] = 1;
 }
 
-// prefetch into the memory-side cache: plain (allocating) loads, result discarded
-template <int U>
-__global__ __launch_bounds__(256) void prefetch_read(const u32x4* __restrict__ p, size_t nvec, uint32_t* out) {
-    u32x4 acc = {0, 0, 0, 0};
-    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256 * U) {
-        u32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (i + u * 256 < nvec) ? p[i + u * 256] : u32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc ^= v[u];
-    }
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[threadIdx.x] = 1;
-}
-
 struct Layer { void *qw, *sc, *sz, *ow; };
 
 __global__ void fill_random(uint32_t* p, size_t n, uint32_t seed, uint32_t andmask, uint32_t ormask) {
@@ -145,50 +131,6 @@ void timeline(std::vector<Layer>& Ls, void* x, void* y, int N, int K, int nblk) 
     CK(hipFree(dbg)); CK(hipFree(dbg2));
 }
 
-// chain of GEMV launches (distinct layers) on one stream, optionally with the NEXT layer's weights being pulled into
-// the Infinity Cache by a side-stream kernel that runs concurrently with the current GEMV
-template <int NW, int D>
-void prefetch_experiment(std::vector<Layer>& Ls, void* x, void* y, int N, int K, double bytes, int pf_grid, uint32_t* out) {
-    const int L = (int)Ls.size();
-    const int nsets = N / 16;
-    const int nblk = nsets < 512 ? nsets : 256 * ((nsets + 384) / 768);
-    const int rs_cap = (nsets + nblk - 1) / nblk;
-    auto kern = gemv_w4_mfma_kernel<NW, 1, D, true, false, 1, 0>;
-    size_t smem = gemv_mfma_smem_bytes(NW, 1, K, 128, rs_cap);
-    hipStream_t s0, s1;
-    CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-    std::vector<hipEvent_t> ev(L);
-    for (auto& evt : ev) CK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
-    hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
-    const size_t wbytes = (size_t)N * K / 2;
-    for (int mode = 0; mode < 2; ++mode) {
-        float best = 1e9f;
-        for (int rep = 0; rep < 6; ++rep) {
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(t0, s0));
-            for (int r2 = 0; r2 < 4; ++r2)
-                for (int l2 = 0; l2 < L; ++l2) {
-                    if (mode == 1) {
-                        CK(hipEventRecord(ev[l2], s0));            // "GEMV l2 is about to start"
-                        CK(hipStreamWaitEvent(s1, ev[l2], 0));
-                        const int nx = (l2 + 1) % L;
-                        hipLaunchKernelGGL(prefetch_read<8>, dim3(pf_grid), dim3(256), 0, s1, (const u32x4*)Ls[nx].qw, wbytes / 16, out);
-                    }
-                    GemvArgs a{(const f16*)x, (const uint8_t*)Ls[l2].qw, (const f16*)Ls[l2].sc, (const f16*)Ls[l2].sz, (const f16*)Ls[l2].ow,
-                               nullptr, nullptr, nullptr, (f16*)y, N, K, 128, 128, 7, (const f16*)x, 1e-5f, nullptr, nullptr, nullptr, nullptr, 1};
-                    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, s0, a, rs_cap);
-                }
-            CK(hipEventRecord(t1, s0));
-            CK(hipEventSynchronize(t1));
-            CK(hipDeviceSynchronize());
-            float ms; CK(hipEventElapsedTime(&ms, t0, t1));
-            if (ms < best) best = ms;
-        }
-        const float us = best * 1e3f / (4 * L);
-        printf("  chain N=%d K=%d %s (pf grid %d): %7.2f us/launch  %6.0f GB/s\n", N, K, mode ? "with MALL prefetch of next layer" : "plain", pf_grid, us, bytes / us / 1e3);
-    }
-}
-
 int main(int argc, char** argv) {
     const int L = 12;
     int shapes[4][2] = {{4096, 4096}, {11008, 4096}, {22016, 4096}, {4096, 11008}};
@@ -222,9 +164,9 @@ int main(int argc, char** argv) {
         double bytes = (double)N * (K - 128) / 2 + 2.0 * (K / 128) * N * 2 + (double)N * 128 * 2 + 2 * K + 2 * N;
         printf("N=%d K=%d algorithmic bytes %.0f\n", N, K, bytes);
         const int nb = N / 16 < 512 ? N / 16 : 256 * ((N / 16 + 384) / 768);
-        run_mfma<8, 4, 0, 1>("mfma +rmsnorm", Ls, x, y, N, K, bytes, nb);
-        prefetch_experiment<8, 4>(Ls, x, y, N, K, bytes, 256, out);
-        prefetch_experiment<8, 4>(Ls, x, y, N, K, bytes, 1024, out);
+        run_mfma<8, 4, 0, 1>("mfma +rmsnorm D=4", Ls, x, y, N, K, bytes, nb);
+        run_mfma<8, 4, 0, 0>("mfma plain D=4", Ls, x, y, N, K, bytes, nb);
+        run_mfma<8, 4, 0, 2>("mfma silu*up D=4", Ls, x, y, N, K, bytes, nb);
         for (auto& l : Ls) { (void)hipFree(l.qw); (void)hipFree(l.sc); (void)hipFree(l.sz); (void)hipFree(l.ow); }
         (void)hipFree(x); (void)hipFree(y);
     }
