@@ -86,7 +86,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    # QEFT_BENCH_FORCE_TP=1: rehearse the multi-GPU launch sequence (sharded linears + RCCL all-gathers inside the
+    # graph) with a group of one rank on a one-GPU box
+    force_tp = os.environ.get("QEFT_BENCH_FORCE_TP") == "1" and "RANK" in os.environ
+    if world > 1 or force_tp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         group = dist.group.WORLD
@@ -172,7 +175,7 @@ def main():
             "config": {"workload": f"{shape.name} w4 g{shape.group_size} r{shape.n_out} full decode step, batch 1, "
                                    f"greedy, KV context {args.warmup}..{args.warmup + args.steps} tokens",
                        "layers": shape.n_layers, "hipgraph": graph_ok,
-                       "parallelism": f"tp{world} row-sharded QuantLinear + all-gather" if world > 1 else "single GPU",
+                       "parallelism": f"tp{world} row-sharded QuantLinear + all-gather" if group is not None else "single GPU",
                        "build_s": round(t_build, 1), "last_token": last_tok},
         }
         if roof:
@@ -183,7 +186,7 @@ def main():
             except Exception as e:
                 print(f"[bench] cpu baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

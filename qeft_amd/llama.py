@@ -216,7 +216,8 @@ class DecodeEngine:
         self.tp_group = tp_group
         self.P = dist.get_world_size(tp_group) if tp_group is not None else 1
         self.rank = dist.get_rank(tp_group) if tp_group is not None else 0
-        P = self.P
+        self.tp = tp_group is not None      # a 1-rank group still runs the sharded launch sequence + collectives
+        P, tp = self.P, self.tp
         f16 = dict(dtype=torch.float16, device=dev)
         self.tok = torch.zeros(1, dtype=torch.long, device=dev)
         self.pos = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -230,12 +231,12 @@ class DecodeEngine:
         self.att = torch.zeros(s.hidden, **f16)
         self.act = torch.zeros(s.inter, **f16)
         # local (per-rank) slices; with P == 1 they alias the full buffers
-        self.qkv_loc = torch.zeros(self.hs + 2 * self.kvs, **f16) if P > 1 else None
-        self.qkv_all = torch.zeros(P, self.hs + 2 * self.kvs, **f16) if P > 1 else None
-        self.h_loc = torch.zeros(self.hs, **f16) if P > 1 else None
+        self.qkv_loc = torch.zeros(self.hs + 2 * self.kvs, **f16) if tp else None
+        self.qkv_all = torch.zeros(P, self.hs + 2 * self.kvs, **f16) if tp else None
+        self.h_loc = torch.zeros(self.hs, **f16) if tp else None
         self.gate_loc = torch.zeros(self.its, **f16)
         self.up_loc = torch.zeros(self.its, **f16)
-        self.act_loc = torch.zeros(self.its, **f16) if P > 1 else self.act
+        self.act_loc = torch.zeros(self.its, **f16) if tp else self.act
         self.hn = torch.zeros(1, s.hidden, **f16)
         self.logits = torch.zeros(1, s.vocab, **f16)
         self.kc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
@@ -257,7 +258,7 @@ class DecodeEngine:
         for L in model.model.layers:
             a, mlp = L.self_attn, L.mlp
             names = dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.o_proj, g=mlp.gate_proj, u=mlp.up_proj, d=mlp.down_proj)
-            if P > 1:
+            if tp:
                 names = {kk: shard_quantlinear(vv, self.rank, P).to(dev) for kk, vv in names.items()}
             self.lin.append(names)
             o = names["o"]
@@ -270,7 +271,7 @@ class DecodeEngine:
             qkv = [names["q"], names["k"], names["v"]]
             gu = [names["g"], names["u"]]
             no = s.n_out
-            if P > 1:
+            if tp:
                 qkv_y = [self.qkv_loc[:self.hs], self.qkv_loc[self.hs:self.hs + self.kvs], self.qkv_loc[self.hs + self.kvs:]]
             else:
                 qkv_y = [self.q, self.k, self.v]
@@ -307,7 +308,7 @@ class DecodeEngine:
     @torch.no_grad()
     def _launch_token(self, linears_only=False):
         import torch.distributed as dist
-        s, lib, ck, P = self.m.shape, self.lib, _lib.check, self.P
+        s, lib, ck, P, tp = self.m.shape, self.lib, _lib.check, self.P, self.tp
         st = torch.cuda.current_stream(self.dev).cuda_stream
         h, h2 = self.hbuf
         if not linears_only:
@@ -324,7 +325,7 @@ class DecodeEngine:
             qw, sc, sz, ow, ys, ns, szp = pk["qkv"]
             ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None,
                                       szp, ys, ns, s.hidden, g, no, st))
-            if P > 1:
+            if tp:
                 dist.all_gather_into_tensor(self.qkv_all.view(-1), self.qkv_loc, group=self.tp_group)
                 self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
                 self.k.view(P, self.kvs).copy_(self.qkv_all[:, self.hs:self.hs + self.kvs])
@@ -341,7 +342,7 @@ class DecodeEngine:
             ow_o = o.oweight_interleaved.data_ptr() if no else None
             szp_o = o._szp(o.scales)
             szp_o = szp_o.data_ptr() if szp_o is not None else None
-            if P > 1:
+            if tp:
                 ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
                                           o.scaled_zeros.data_ptr(), ow_o, None, ids, h[r0:r0 + self.hs].data_ptr(), szp_o,
                                           self.h_loc.data_ptr(), 1, self.hs, s.hidden, g, no, st))
@@ -354,7 +355,7 @@ class DecodeEngine:
             qw, sc, sz, ow, ys, ns, szp = pk["gu"]
             ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz,
                                       ow, None, szp, ys, ns, s.hidden, g, no, st))
-            if P > 1:
+            if tp:
                 if not linears_only:
                     ck(lib.qeft_silu_mul(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), self.act_loc.data_ptr(),
                                          self.its, st))
@@ -363,7 +364,7 @@ class DecodeEngine:
             ow_d = d.oweight_interleaved.data_ptr() if no else None
             szp_d = d._szp(d.scales)
             szp_d = szp_d.data_ptr() if szp_d is not None else None
-            if P > 1:
+            if tp:
                 ck(lib.qeft_gemv_w4_fused(self.act.data_ptr(), d.qweight.data_ptr(), d.scales.data_ptr(),
                                           d.scaled_zeros.data_ptr(), ow_d, None, None, h[r0:r0 + self.hs].data_ptr(),
                                           szp_d, self.h_loc.data_ptr(), 1, self.hs, s.inter, g, no, st))
