@@ -4,9 +4,10 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
 
 Workload (BASELINE.json configs[1]): Llama-2-7B shapes, w4 g128 r128, batch 1.  A "step" is ONE decode token of
-the whole model: 32 layers x (RMSNorm, q|k|v grouped GEMV, rotary+KV-append+attention, o_proj GEMV with the o_proj
-gather and the residual, RMSNorm, gate|up grouped GEMV, SiLU*mul, down_proj GEMV with the residual), final norm,
-fp16 lm_head, greedy argmax — captured once into a hipGraph and replayed.  Weights are synthetic (seeded), inputs
+the whole model: token begin (embedding row + rotary row), 32 layers x 5 launches (q|k|v grouped GEMV with the RMSNorm
+folded in, rotary+KV-append+attention writing in o_proj's column order, o_proj GEMV + residual, gate|up grouped GEMV
+with the RMSNorm folded in, down_proj GEMV with SiLU*up folded in + residual), final norm, fp16 lm_head, token end
+(greedy argmax, pos += 1) — captured once into a hipGraph and replayed.  Weights are synthetic (seeded), inputs
 are resident in HBM; the timed region is K graph replays bracketed by barrier + synchronize.
 
 N > 1: every quantized linear is row-sharded over the N ranks and one RCCL all-gather per linear rebuilds the
@@ -15,8 +16,8 @@ activations (strong scaling: the model is fixed).
 The same JSON line carries
   roofline      for the dominant kernel (the W4 GEMV): algorithmic bytes of all GEMV launches of one token /
                 their HIP-event-timed duration (the token's GEMV launches replayed back to back from a graph on the
-                launch stream; the event time includes the ~1.3 us inter-kernel gaps, so it under-states the
-                per-kernel rate rocprofv3 reports), against 8 TB/s.
+                launch stream; the event time includes the ~1.3 us inter-kernel gaps, as rocprofv3's kernel-trace
+                durations on this stack do -- the two agree), against 8 TB/s.
   cpu_baseline  the reference's CPU path (dense nn.Linear on the dequantised weights, oracle/) timed on the host cores
                 for the 7 linears of one layer, scaled to a token.
 """

@@ -34,7 +34,15 @@ hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, 
 }  // namespace qeft
 
 static thread_local int g_last_hip_error = 0;
-static const int kSmallM = 48;   // rows up to which the GEMM entry uses the MFMA GEMV (measured crossover)
+// Few rows: the GEMM entry streams the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
+// Measured crossover (tools/bench_gemm.py): one 16-row slice costs ~13 us per 2^24 weights, the
+// GEMM at M <= 128 is latency-bound at ~54 us per 4096 of K whatever N is -> the GEMV route wins while
+// slices * N <= 16384 (always for one slice).
+static bool small_m_route(int m, int n) {
+    if (m <= 16) return true;
+    const int slices = (m + 15) / 16;
+    return m <= 64 && (long long)slices * n <= 16384;
+}
 
 static int finish(hipError_t e) {
     if (e == hipSuccess) return QEFT_OK;
@@ -135,7 +143,7 @@ int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const v
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
-    if (m <= kSmallM && (n_out > 0) == (oweight != nullptr)) {
+    if (small_m_route(m, n) && (n_out > 0) == (oweight != nullptr)) {
         // few rows: stream the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
         // (gemm_4bit semantics with oweight == NULL and a non-zero slice -- dead nibbles -- stays on the GEMM kernel.)
         qeft::GemvArgs a{};
