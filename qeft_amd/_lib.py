@@ -5,6 +5,12 @@ There is no CPU fallback: if the library is missing, or an entry point fails, th
 import ctypes
 import os
 
+# torch must be in the process BEFORE the library is loaded: torch ships its own libamdhip64 and the library links
+# the system one under the same soname.  Whichever loads first serves both; if it is the system copy, torch's
+# streams / allocations and this library's kernels end up in two HIP runtimes and every launch fails
+# (hipErrorNoDevice).  Loading torch first makes its runtime the only one.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # QEFT_HIP_LIB: load another build of the same ABI (A/B timing of two builds on one GPU box); never a fallback
 LIB_PATH = os.environ.get("QEFT_HIP_LIB") or os.path.join(_HERE, "lib", "libqeft_hip.so")

@@ -83,3 +83,14 @@ def test_product_does_not_import_oracle():
             [os.path.join(ROOT, "qeft_cuda.py")]:
         src = open(path).read()
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{path} references the oracle"
+
+
+def test_binding_puts_torch_hip_runtime_first():
+    """The library links the system libamdhip64, torch ships its own: torch has to be loaded before the library or the
+    process ends up with two HIP runtimes (launches then fail with hipErrorNoDevice, seen as build() + smoke() in one
+    process).  The binding module therefore imports torch itself."""
+    import subprocess
+    import sys
+    code = "import sys; from qeft_amd import _lib; assert 'torch' in sys.modules; print('ok')"
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
