@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--bits", type=int, default=4, choices=[3, 4],
+                    help="4: the reference's w4 checkpoint layout (BASELINE configs 1-4, the default); "
+                         "3: this build's 3-bit extension layout (config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -98,7 +101,7 @@ def main():
     from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, DecodeEngine, QuantLlama, tiny_shape
     import dataclasses
     base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B, "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
-    shape = dataclasses.replace(base, max_seq=max(512, (args.warmup + args.steps + 8 + 15) // 16 * 16))
+    shape = dataclasses.replace(base, max_seq=max(512, (args.warmup + args.steps + 8 + 15) // 16 * 16), bits=args.bits)
 
     t_build = time.time()
     model = QuantLlama(shape, dev, seed=0, fast_init=True)
@@ -169,11 +172,12 @@ def main():
     if rank == 0:
         ms = dt * 1e3 / args.steps
         out = {
-            "metric": "decode tokens/sec, Llama-2-7B w4 g128 r128" if args.model == "7b" else f"decode tokens/sec, {shape.name} w4 g128 r128",
+            "metric": "decode tokens/sec, Llama-2-7B w4 g128 r128" if (args.model == "7b" and args.bits == 4)
+            else f"decode tokens/sec, {shape.name} w{args.bits} g128 r128",
             "value": round(args.steps / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{shape.name} w4 g{shape.group_size} r{shape.n_out} full decode step, batch 1, "
+            "config": {"workload": f"{shape.name} w{args.bits} g{shape.group_size} r{shape.n_out} full decode step, batch 1, "
                                    f"greedy, KV context {args.warmup}..{args.warmup + args.steps} tokens",
                        "layers": shape.n_layers, "hipgraph": graph_ok,
                        "parallelism": f"tp{world} row-sharded QuantLinear + all-gather" if group is not None else "single GPU",

@@ -145,6 +145,30 @@ int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const voi
                           int tab_rows, void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out,
                           void* workspace, int n_split, int n_heads, int n_kv_heads, int max_seq, qeft_stream_t stream);
 
+/* ---- 3-bit EXTENSION (BASELINE config 5).  The reference cannot pack or run 3 bits (QuantLinear asserts
+ * bits == 4, qlinear.py:127; its quantiser can produce them, quant.py:8-10 with maxq = 7), so the layout is this
+ * library's own, shaped by the decode GEMV (oracle/qeft_oracle.py: pack_w3 / w3_position):
+ *   qweight3  int32 [N/16, ((K - n_out)/128) * 192]   12 bytes per (row, 32-k chunk), 16 rows x 128 k contiguous;
+ *                                                      the fp16 outlier columns have no 3-bit fields
+ * scales / scaled_zeros / oweight / oweight_il / sz_packed are as for 4 bits.
+ * Requirements: N % 16 == 0, K % 128 == 0, n_out % 128 == 0, n_out < K, group size 128 or K.
+ * qeft_gemv_w3        y[m,N] = x[m,K] . W^T (+ bias, + residual), any m >= 1 (16 rows per weight pass)
+ * qeft_gemv_w3_group / qeft_gemv_w3_silu   as their w4 namesakes
+ * qeft_expand_w3      rewrites the stream into the 4-bit checkpoint layout int16 [N/4, K] (dead zero nibbles under
+ *                     the fp16 columns) so that qeft_gemm_w4 / qeft_gemm_w4_dx / qeft_dequant_w4 serve 3-bit layers:
+ *                     reads 3/8 byte and writes 1/2 byte per weight. */
+int qeft_gemv_w3(const void* x, const void* qweight3, const void* scales, const void* scaled_zeros,
+                 const void* oweight_il, const void* bias, const void* residual, const void* sz_packed, void* y, int m,
+                 int n, int k, int group_size, int n_out, qeft_stream_t stream);
+int qeft_gemv_w3_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
+                       const void* const* qweight3, const void* const* scales, const void* const* scaled_zeros,
+                       const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream);
+int qeft_gemv_w3_silu(const void* gate, const void* up, const void* qweight3, const void* scales,
+                      const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
+                      const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream);
+int qeft_expand_w3(const void* qweight3, void* qweight4, int n, int k, int n_out, qeft_stream_t stream);
+
 /* Token boundary of the decode loop (main.py:340-371, benchmark.py:293-338).
  * begin: h[hidden] = embed[*tok] (tok: device int64, clamped to the vocabulary) and, if rope_row != NULL,
  *        rope_row[128] = rope_tab[*pos] (rope_tab fp32 [max_seq][cos 64 | sin 64]) for qeft_rope_attn_decode(tab_rows = 1).

@@ -35,6 +35,10 @@ SIGNATURES = {
     "qeft_gemv_w4_silu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_rmsnorm": [_p, _p, _p, _p, _p, _i, _i, ctypes.c_float, _p],
     "qeft_silu_mul": [_p, _p, _p, _i, _p],
+    "qeft_gemv_w3": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemv_w3_group": [_p, _p, ctypes.c_float, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_gemv_w3_silu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "qeft_expand_w3": [_p, _p, _i, _i, _i, _p],
     "qeft_attn_workspace_bytes": [_i, _i],
     "qeft_token_begin": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_token_end": [_p, _p, _p, _i, _i, _p],

@@ -10,6 +10,10 @@ hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
 hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
 hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st);
 hipError_t gemv_w4_smallm_dispatch(const GemvArgs& a, int m, hipStream_t st);
+hipError_t gemv_w3_dispatch(const GemvArgs& a, int m, hipStream_t st);
+hipError_t gemv_w3_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
+hipError_t gemv_w3_silu_dispatch(const GemvArgs& a, hipStream_t st);
+hipError_t expand_w3_launch(const void* q3, void* q4, int N, int K, int n_out, hipStream_t st);
 hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int H,
                           float eps, hipStream_t st);
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
@@ -82,8 +86,8 @@ const char* qeft_error_string(int code) {
 static int gemv_fused_impl(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                            const void* oweight_il, const void* bias, const int* reorder_ids, const void* residual,
                            const void* sz_packed, void* y, int m, int n, int k, int group_size, int n_out,
-                           qeft_stream_t stream) {
-    if (m < 1 || m > 7) return QEFT_ERR_BATCH;
+                           qeft_stream_t stream, int bits = 4) {
+    if (m < 1 || (bits == 4 && m > 7)) return QEFT_ERR_BATCH;
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight_il))) return QEFT_ERR_ALIGN;
@@ -111,6 +115,10 @@ static int gemv_fused_impl(const void* x, const void* qweight, const void* scale
     if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
+    if (bits == 3) {
+        if (m < 1 || reorder_ids) return QEFT_ERR_SHAPE;   // the gather is the caller's (qlinear.py:275) for w3
+        return finish(qeft::gemv_w3_dispatch(a, m, (hipStream_t)stream));
+    }
     return finish(qeft::gemv_w4_dispatch(a, m, (hipStream_t)stream));
 }
 
@@ -215,10 +223,10 @@ int qeft_pack_oweight(const void* oweight, void* oweight_il, int n, int n_out, q
     return finish(qeft::pack_oweight_launch(oweight, oweight_il, n, n_out, (hipStream_t)stream));
 }
 
-int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
-                       const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
-                       const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
-                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream) {
+static int gemv_group_impl(const void* x, const void* norm_gamma, float norm_eps, int nparts,
+                           const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
+                           const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
+                           void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream, int bits) {
     if (nparts < 1 || nparts > 3) return QEFT_ERR_SHAPE;
     if (!x || !qweight || !scales || !scaled_zeros || !y || !n) return QEFT_ERR_NULL;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;
@@ -247,12 +255,30 @@ int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, in
     if (norm_gamma && !aligned16(norm_gamma)) return QEFT_ERR_ALIGN;
     g.xt_aux = (const qeft::f16*)norm_gamma;
     g.xt_eps = norm_eps;
+    if (bits == 3) return finish(qeft::gemv_w3_group_dispatch(g, nparts, (hipStream_t)stream));
     return finish(qeft::gemv_w4_group_dispatch(g, nparts, (hipStream_t)stream));
 }
 
-int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, const void* scales,
-                      const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
-                      const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+int qeft_gemv_w4_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
+                       const void* const* qweight, const void* const* scales, const void* const* scaled_zeros,
+                       const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    return gemv_group_impl(x, norm_gamma, norm_eps, nparts, qweight, scales, scaled_zeros, oweight_il, bias, sz_packed, y,
+                           n, k, group_size, n_out, stream, 4);
+}
+
+int qeft_gemv_w3_group(const void* x, const void* norm_gamma, float norm_eps, int nparts,
+                       const void* const* qweight3, const void* const* scales, const void* const* scaled_zeros,
+                       const void* const* oweight_il, const void* const* bias, const void* const* sz_packed,
+                       void* const* y, const int* n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    return gemv_group_impl(x, norm_gamma, norm_eps, nparts, qweight3, scales, scaled_zeros, oweight_il, bias, sz_packed,
+                           y, n, k, group_size, n_out, stream, 3);
+}
+
+static int gemv_silu_impl(const void* gate, const void* up, const void* qweight, const void* scales,
+                          const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
+                          const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream,
+                          int bits) {
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (!gate || !up || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
@@ -281,7 +307,36 @@ int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, con
     a.dbg2 = nullptr;
     a.ow_plain = nullptr;
     a.m_rt = 1;
+    if (bits == 3) return finish(qeft::gemv_w3_silu_dispatch(a, (hipStream_t)stream));
     return finish(qeft::gemv_w4_silu_dispatch(a, (hipStream_t)stream));
+}
+
+int qeft_gemv_w4_silu(const void* gate, const void* up, const void* qweight, const void* scales,
+                      const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
+                      const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    return gemv_silu_impl(gate, up, qweight, scales, scaled_zeros, oweight_il, bias, residual, sz_packed, y, n, k,
+                          group_size, n_out, stream, 4);
+}
+
+int qeft_gemv_w3_silu(const void* gate, const void* up, const void* qweight3, const void* scales,
+                      const void* scaled_zeros, const void* oweight_il, const void* bias, const void* residual,
+                      const void* sz_packed, void* y, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    return gemv_silu_impl(gate, up, qweight3, scales, scaled_zeros, oweight_il, bias, residual, sz_packed, y, n, k,
+                          group_size, n_out, stream, 3);
+}
+
+int qeft_gemv_w3(const void* x, const void* qweight3, const void* scales, const void* scaled_zeros,
+                 const void* oweight_il, const void* bias, const void* residual, const void* sz_packed, void* y, int m,
+                 int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    return gemv_fused_impl(x, qweight3, scales, scaled_zeros, oweight_il, bias, nullptr, residual, sz_packed, y, m, n, k,
+                           group_size, n_out, stream, 3);
+}
+
+int qeft_expand_w3(const void* qweight3, void* qweight4, int n, int k, int n_out, qeft_stream_t stream) {
+    if (n <= 0 || k <= 0 || n % 16 != 0 || k % 128 != 0 || n_out < 0 || n_out % 128 != 0 || n_out >= k) return QEFT_ERR_SHAPE;
+    if (!qweight3 || !qweight4) return QEFT_ERR_NULL;
+    if (!aligned16(qweight4) || (reinterpret_cast<uintptr_t>(qweight3) & 3u)) return QEFT_ERR_ALIGN;
+    return finish(qeft::expand_w3_launch(qweight3, qweight4, n, k, n_out, (hipStream_t)stream));
 }
 
 int qeft_rmsnorm(const void* x, const void* add, const void* gamma, void* res_out, void* y, int m, int hidden,

@@ -20,6 +20,8 @@
 //   acc[m][n] += s[n] * (P[m][n] - A[m]) + sz[n] * B[m],   A = 1024 * sum x', B = sum x over the step's 128 k.
 // 5 integer ops per word + 1 MFMA + 1 LDS read per 8 weights per lane.
 #pragma once
+#include <type_traits>
+
 #include "gemv_w4_kernel.h"
 
 namespace qeft {
@@ -48,8 +50,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // correction sums) is paid once per block, so wide layers are launched with fewer, longer-lived blocks (a few per
 // CU): one prologue then feeds RS x more weight bytes, and a wave walks its (row set, step) pairs as ONE sequence so
 // the register ring never drains between row sets.
-template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
+template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0, int BITS = 4>
 __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int set0, const int RS, const int rs_cap) {
+    static_assert(BITS == 4 || BITS == 3, "4-bit checkpoint layout or the 3-bit extension layout (oracle: pack_w3)");
     // this block owns the 16-row sets [set0, set0 + RS) of the layer; LDS is carved for rs_cap sets (launch constant)
     static_assert(XT == 0 || (M == 1 && !XG), "x transforms are for the batch-1 decode engine");
     constexpr int kWaves = NW, kBlock = NW * 64;
@@ -135,15 +138,22 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
 
     // ---- 2. weight stream: ring of D steps per wave (steps wave, wave+NW, ...), branch-free, oldest first
     // The wave's work is the sequence t = 0 .. RS*nsw-1 of (row set rs = t / nsw, step s = wave + NW * (t % nsw)).
-    u32x4 ring[D];
-    const uint8_t* wbase = a.qw + (size_t)(rg0 + (nl >> 2)) * a.K * 2 + (kc >> 1) * 128 + (nl & 3) * 32 + (kc & 1) * 16;
-    const uint32_t rs_bytes = (uint32_t)a.K * 8u;                      // 4 row-groups of 2K bytes per row set
+    // BITS == 3: 12 bytes per lane (three words = the 32 3-bit weights of (row nl, chunk kc)), a step of one row set
+    // is 768 contiguous bytes, a row set (K - n_out) / 128 steps; the fp16 columns have no fields (oracle: pack_w3).
+    typedef typename std::conditional<BITS == 3, u32x3_u, u32x4>::type ring_t;
+    ring_t ring[D];
+    const uint32_t step_bytes = BITS == 3 ? 768u : 256u;
+    const uint8_t* wbase = BITS == 3
+        ? a.qw + (size_t)set0 * nfull * 768u + lane * 12
+        : a.qw + (size_t)(rg0 + (nl >> 2)) * a.K * 2 + (kc >> 1) * 128 + (nl & 3) * 32 + (kc & 1) * 16;
+    const uint32_t rs_bytes = BITS == 3 ? (uint32_t)nfull * 768u : (uint32_t)a.K * 8u;   // bytes per row set
+    const uint32_t last_off = BITS == 3 ? (uint32_t)max(nfull - 1, 0) * 768u : (uint32_t)a.K * 2 - 256u;
     int p_rs = 0, p_i = 0;                                             // (row set, index) of the next step to issue
-    auto issue = [&](u32x4& b) {
-        // past the end (or a wave without ring steps): harmless re-read of a valid address inside the row-group
+    auto issue = [&](ring_t& b) {
+        // past the end (or a wave without ring steps): harmless re-read of a valid address inside the row set
         const int irs = min(p_rs, RS - 1);
-        const uint32_t woff = min((uint32_t)(wave + p_i * kWaves) * 256u, (uint32_t)a.K * 2 - 256u);
-        b = __builtin_nontemporal_load((const u32x4*)(wbase + (size_t)irs * rs_bytes + woff));
+        const uint32_t woff = min((uint32_t)(wave + p_i * kWaves) * step_bytes, last_off);
+        b = __builtin_nontemporal_load((const ring_t*)(wbase + (size_t)irs * rs_bytes + woff));
         if (++p_i >= nsw) { p_i = 0; ++p_rs; }
     };
 #pragma unroll
@@ -237,14 +247,29 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             float bsum = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bsum += (float)as_h2(xv[j])[0] + (float)as_h2(xv[j])[1];
-            const int q = (k >> 3) & 3;                       // quarter of the 32-k chunk
-            const bool hi = (q & 1) && (k < kq);              // k%32 in [8,16) or [24,32): meets the high nibbles
             float asum = bsum;
-            if (hi) {
+            if (BITS == 4) {
+                const int q = (k >> 3) & 3;                       // quarter of the 32-k chunk
+                const bool hi = (q & 1) && (k < kq);              // k%32 in [8,16) or [24,32): meets the high nibbles
+                if (hi) {
+                    asum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const h2 t = as_h2(xv[j]) * k16th;
+                        xv[j] = as_u32(t);
+                        asum += (float)t[0] + (float)t[1];
+                    }
+                }
+            } else if (k < kq) {
+                // 3-bit: pair e = (k % 32) / 2 sits at bit 3 * (e % 5) (mod 9) of its half-word -> 1024 + q * 2^sh
                 asum = 0.f;
+                const int e0 = (k >> 1) & 15;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const h2 t = as_h2(xv[j]) * k16th;
+                    const int e = e0 + j;
+                    const int sh = (e == 15) ? 0 : ((e % 5) % 3) * 3;
+                    const f16 f = (f16)(1.0f / (float)(1 << sh));
+                    const h2 t = as_h2(xv[j]) * h2{f, f};
                     xv[j] = as_u32(t);
                     asum += (float)t[0] + (float)t[1];
                 }
@@ -345,7 +370,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             o.ab[j] = *(const float2*)(corr + ((size_t)m * nsteps + s) * 2);
         }
     };
-    auto consume = [&](const u32x4& wv, const StepOps& cur, StepOps& nxt) {
+    auto consume = [&](const ring_t& wv, const StepOps& cur, StepOps& nxt) {
         if (c_i == 0) outlier_steps(c_rs);
         const int rs_now = c_rs;
         const bool last_of_set = c_i + 1 >= nsw;
@@ -357,13 +382,34 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             f32x4 P0 = {0.f, 0.f, 0.f, 0.f}, P1 = {0.f, 0.f, 0.f, 0.f};   // two chains: MFMA latency is exposed at 2 waves/SIMD
             // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
             u32x4 bf[4];
+            if (BITS == 4) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t v = wv[w], t = v >> 8;
-                bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
-                bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q   (x' = x / 16 on these k)
-                bf[2][w] = (t & 0x000f000fu) | MAGIC;
-                bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t v = wv[w], t = v >> 8;
+                    bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
+                    bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q   (x' = x / 16 on these k)
+                    bf[2][w] = (t & 0x000f000fu) | MAGIC;
+                    bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+                }
+            } else {
+                // pair e = 4 j + w (k = 2e, 2e+1 of the chunk): word e / 5, field e % 5; pair 15 from bits 15 / 31
+                uint32_t ext[16];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t v = wv[i], t = v >> 9;
+                    ext[5 * i + 0] = (v & 0x00070007u) | MAGIC;   // 1024 + q
+                    ext[5 * i + 1] = (v & 0x00380038u) | MAGIC;   // 1024 + 8 q    (x' = x / 8)
+                    ext[5 * i + 2] = (v & 0x01c001c0u) | MAGIC;   // 1024 + 64 q   (x' = x / 64)
+                    ext[5 * i + 3] = (t & 0x00070007u) | MAGIC;
+                    ext[5 * i + 4] = (t & 0x00380038u) | MAGIC;
+                }
+                ext[15] = ((wv[0] >> 15) & 0x00010001u) | MAGIC;
+                ext[15] |= (wv[1] >> 14) & 0x00020002u;
+                ext[15] |= (wv[2] >> 13) & 0x00040004u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) bf[j][w] = ext[4 * j + w];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -463,17 +509,17 @@ __device__ __forceinline__ void block_sets(int b, int nblk, int nsets, int& set0
     cnt = q + (b < r ? 1 : 0);
 }
 
-template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0>
+template <int NW, int M, int D, bool OUTL, bool XG, int XT = 0, int ABL = 0, int BITS = 4>
 __global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_kernel(GemvArgs a, int rs_cap) {
     const int b = (ABL & 8) ? (int)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);
     int set0, cnt;
     block_sets(b, gridDim.x, a.N / 16, set0, cnt);
-    gemv_w4_mfma_body<NW, M, D, OUTL, XG, XT, ABL>(a, set0, cnt, rs_cap);
+    gemv_w4_mfma_body<NW, M, D, OUTL, XG, XT, ABL, BITS>(a, set0, cnt, rs_cap);
 }
 
 // Several linears that share the same input (q/k/v, gate/up) in ONE launch, batch 1: blocks [blk_end[p-1], blk_end[p])
 // work on part p and split its row sets evenly.
-template <int NW, int D, bool OUTL, int XT = 0>
+template <int NW, int D, bool OUTL, int XT = 0, int BITS = 4>
 __global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupArgs g, int rs_cap) {
     const int gb = xcd_contiguous_block(blockIdx.x, gridDim.x);
     int p = 0, blk = gb, nb = g.blk_end[0];
@@ -505,7 +551,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_w4_mfma_group_kernel(GemvGroupAr
     a.m_rt = 1;
     int set0, cnt;
     block_sets(blk, nb, a.N / 16, set0, cnt);
-    gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0>(a, set0, cnt, rs_cap);
+    gemv_w4_mfma_body<NW, 1, D, OUTL, false, XT, 0, BITS>(a, set0, cnt, rs_cap);
 }
 
 }  // namespace qeft

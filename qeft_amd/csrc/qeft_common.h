@@ -11,6 +11,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_u __attribute__((aligned(4)));   // 12-byte records of the 3-bit layout: dword alignment only
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -39,6 +39,7 @@ class LlamaShape:
     n_out: int = 128
     group_size: int = 128
     name: str = "llama"
+    bits: int = 4          # 3: this build's 3-bit extension layout (qlinear.pack_w3)
 
     @property
     def head_dim(self):
@@ -57,18 +58,19 @@ def tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=512, max_seq=
 # synthetic packed layers: W ~ N(0, 0.02^2), per-group asymmetric min-max INT4, last n_out
 # columns kept fp16
 # ----------------------------------------------------------------------------------------------------
-def synthetic_quantlinear(name, in_f, out_f, n_out, group_size, seed, device, outlieridx=None, fast_init=False):
+def synthetic_quantlinear(name, in_f, out_f, n_out, group_size, seed, device, outlieridx=None, fast_init=False,
+                          bits=4):
     # CPU generator: identical weights on every device / rank for a given seed
     gdev = "cpu" if (torch.device(device).type == "cpu" or not fast_init) else device
     gen = torch.Generator(device=gdev).manual_seed(seed)
     w = (torch.randn(out_f, in_f, generator=gen, dtype=torch.float32, device=gdev) * 0.02).to(device).half()
-    scale, zero = minmax_params(w, group_size)
-    wq = fake_quantize(w, scale, zero, group_size).half()
+    scale, zero = minmax_params(w, group_size, bits)
+    wq = fake_quantize(w, scale, zero, group_size, bits).half()
     if n_out > 0:
         wq[:, in_f - n_out:] = w[:, in_f - n_out:]
     lin = nn.Linear(in_f, out_f, bias=False, dtype=torch.float16, device=device)
     lin.weight.data = wq
-    ql = QuantLinear(4, in_f, out_f, False, torch.float16, n_out, group_size, True, name).to(device)
+    ql = QuantLinear(bits, in_f, out_f, False, torch.float16, n_out, group_size, True, name).to(device)
     if outlieridx is None:
         outlieridx = torch.arange(in_f - n_out, in_f, dtype=torch.int32, device=device)
     ql.pack(lin, scale, zero, outlieridx.to(device))
@@ -117,16 +119,16 @@ class QuantLlama(nn.Module):
             L.mlp = _Mlp()
             pre = f"model.layers.{li}."
             sd = 1000 * li + seed * 7919
-            L.self_attn.q_proj = synthetic_quantlinear(pre + "self_attn.q_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 0, device, fast_init=fast_init)
-            L.self_attn.k_proj = synthetic_quantlinear(pre + "self_attn.k_proj", s.hidden, kv, s.n_out, s.group_size, sd + 1, device, fast_init=fast_init)
-            L.self_attn.v_proj = synthetic_quantlinear(pre + "self_attn.v_proj", s.hidden, kv, s.n_out, s.group_size, sd + 2, device, fast_init=fast_init)
+            L.self_attn.q_proj = synthetic_quantlinear(pre + "self_attn.q_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 0, device, fast_init=fast_init, bits=s.bits)
+            L.self_attn.k_proj = synthetic_quantlinear(pre + "self_attn.k_proj", s.hidden, kv, s.n_out, s.group_size, sd + 1, device, fast_init=fast_init, bits=s.bits)
+            L.self_attn.v_proj = synthetic_quantlinear(pre + "self_attn.v_proj", s.hidden, kv, s.n_out, s.group_size, sd + 2, device, fast_init=fast_init, bits=s.bits)
             # o_proj has its OWN outlier columns (per layer, reorder.py:38-46) -> runtime gather of its input
             g2 = torch.Generator(device="cpu").manual_seed(sd + 99)
             oidx = torch.randperm(s.hidden, generator=g2)[:max(s.n_out, 1)].sort().values.to(torch.int32) if s.n_out else None
-            L.self_attn.o_proj = synthetic_quantlinear(pre + "self_attn.o_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 3, device, oidx, fast_init=fast_init)
-            L.mlp.gate_proj = synthetic_quantlinear(pre + "mlp.gate_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 4, device, fast_init=fast_init)
-            L.mlp.up_proj = synthetic_quantlinear(pre + "mlp.up_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 5, device, fast_init=fast_init)
-            L.mlp.down_proj = synthetic_quantlinear(pre + "mlp.down_proj", s.inter, s.hidden, s.n_out, s.group_size, sd + 6, device, fast_init=fast_init)
+            L.self_attn.o_proj = synthetic_quantlinear(pre + "self_attn.o_proj", s.hidden, s.hidden, s.n_out, s.group_size, sd + 3, device, oidx, fast_init=fast_init, bits=s.bits)
+            L.mlp.gate_proj = synthetic_quantlinear(pre + "mlp.gate_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 4, device, fast_init=fast_init, bits=s.bits)
+            L.mlp.up_proj = synthetic_quantlinear(pre + "mlp.up_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 5, device, fast_init=fast_init, bits=s.bits)
+            L.mlp.down_proj = synthetic_quantlinear(pre + "mlp.down_proj", s.inter, s.hidden, s.n_out, s.group_size, sd + 6, device, fast_init=fast_init, bits=s.bits)
             L.input_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
             L.post_attention_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
             layers.append(L)
@@ -150,7 +152,8 @@ class QuantLlama(nn.Module):
             for grp, names in (("self_attn", ("q_proj", "k_proj", "v_proj", "o_proj")), ("mlp", ("gate_proj", "up_proj", "down_proj"))):
                 for n in names:
                     ql = getattr(getattr(L, grp), n)
-                    d[n] = qeft_cuda.dequantize_weight_4bit_qeft(ql.qweight, ql.scales, ql.scaled_zeros,
+                    qw = ql._qweight4().clone() if ql.bits == 3 else ql.qweight
+                    d[n] = qeft_cuda.dequantize_weight_4bit_qeft(qw, ql.scales, ql.scaled_zeros,
                                                                  ql.oweight if ql.outlierfeatures else None).float()
             out.append(d)
         return out
@@ -214,6 +217,7 @@ class DecodeEngine:
         self.dev = dev
         self.lib = _lib.lib()
         self.tp_group = tp_group
+        self.bits = getattr(s, "bits", 4)
         self.P = dist.get_world_size(tp_group) if tp_group is not None else 1
         self.rank = dist.get_rank(tp_group) if tp_group is not None else 0
         self.tp = tp_group is not None      # a 1-rank group still runs the sharded launch sequence + collectives
@@ -301,7 +305,7 @@ class DecodeEngine:
         for names in self.lin:
             for l in names.values():
                 n, k, r, g = l.outfeatures, l.infeatures, l.outlierfeatures, l.group_size
-                tot += n * (k - r) // 2 + 2 * (k // g) * n * 2 + n * r * 2 + 2 * k + 2 * n
+                tot += n * (k - r) * l.bits // 8 + 2 * (k // g) * n * 2 + n * r * 2 + 2 * k + 2 * n
         return tot
 
     # -- the launch sequence ---------------------------------------------------------------------------
@@ -309,6 +313,18 @@ class DecodeEngine:
     def _launch_token(self, linears_only=False):
         import torch.distributed as dist
         s, lib, ck, P, tp = self.m.shape, self.lib, _lib.check, self.P, self.tp
+        w3 = self.bits == 3
+        gemv_group = lib.qeft_gemv_w3_group if w3 else lib.qeft_gemv_w4_group
+        gemv_silu = lib.qeft_gemv_w3_silu if w3 else lib.qeft_gemv_w4_silu
+
+        def gemv_fused(x, ql, ow, residual, szp, y, n, k):
+            """one linear, batch 1, + residual (no gather: the attention kernel already wrote o_proj's column order)"""
+            if w3:
+                return lib.qeft_gemv_w3(x, ql.qweight.data_ptr(), ql.scales.data_ptr(), ql.scaled_zeros.data_ptr(), ow,
+                                        None, residual, szp, y, 1, n, k, g, no, st)
+            return lib.qeft_gemv_w4_fused(x, ql.qweight.data_ptr(), ql.scales.data_ptr(), ql.scaled_zeros.data_ptr(), ow,
+                                          None, None, residual, szp, y, 1, n, k, g, no, st)
+
         st = torch.cuda.current_stream(self.dev).cuda_stream
         h, h2 = self.hbuf
         if not linears_only:
@@ -323,8 +339,8 @@ class DecodeEngine:
             lin, pk = self.lin[li], self.packs[li]
             # input_layernorm is fused into the q|k|v launch (x is normalised while it is staged)
             qw, sc, sz, ow, ys, ns, szp = pk["qkv"]
-            ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None,
-                                      szp, ys, ns, s.hidden, g, no, st))
+            ck(gemv_group(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
+                          s.hidden, g, no, st))
             if tp:
                 dist.all_gather_into_tensor(self.qkv_all.view(-1), self.qkv_loc, group=self.tp_group)
                 self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
@@ -338,23 +354,19 @@ class DecodeEngine:
                                              self.att.data_ptr(), self.attn_ws.data_ptr() if self.attn_ws is not None else None,
                                              self.attn_split, s.n_heads, s.n_kv_heads, s.max_seq, st))
             o = lin["o"]
-            ids = None   # the attention kernel already stored its output in o_proj's column order
             ow_o = o.oweight_interleaved.data_ptr() if no else None
             szp_o = o._szp(o.scales)
             szp_o = szp_o.data_ptr() if szp_o is not None else None
             if tp:
-                ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
-                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h[r0:r0 + self.hs].data_ptr(), szp_o,
-                                          self.h_loc.data_ptr(), 1, self.hs, s.hidden, g, no, st))
+                ck(gemv_fused(self.att.data_ptr(), o, ow_o, h[r0:r0 + self.hs].data_ptr(), szp_o, self.h_loc.data_ptr(),
+                              self.hs, s.hidden))
                 dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
                 h, h2 = h2, h
             else:
-                ck(lib.qeft_gemv_w4_fused(self.att.data_ptr(), o.qweight.data_ptr(), o.scales.data_ptr(),
-                                          o.scaled_zeros.data_ptr(), ow_o, None, ids, h.data_ptr(), szp_o, h.data_ptr(),
-                                          1, s.hidden, s.hidden, g, no, st))
+                ck(gemv_fused(self.att.data_ptr(), o, ow_o, h.data_ptr(), szp_o, h.data_ptr(), s.hidden, s.hidden))
             qw, sc, sz, ow, ys, ns, szp = pk["gu"]
-            ck(lib.qeft_gemv_w4_group(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz,
-                                      ow, None, szp, ys, ns, s.hidden, g, no, st))
+            ck(gemv_group(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz, ow, None, szp,
+                          ys, ns, s.hidden, g, no, st))
             if tp:
                 if not linears_only:
                     ck(lib.qeft_silu_mul(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), self.act_loc.data_ptr(),
@@ -365,16 +377,15 @@ class DecodeEngine:
             szp_d = d._szp(d.scales)
             szp_d = szp_d.data_ptr() if szp_d is not None else None
             if tp:
-                ck(lib.qeft_gemv_w4_fused(self.act.data_ptr(), d.qweight.data_ptr(), d.scales.data_ptr(),
-                                          d.scaled_zeros.data_ptr(), ow_d, None, None, h[r0:r0 + self.hs].data_ptr(),
-                                          szp_d, self.h_loc.data_ptr(), 1, self.hs, s.inter, g, no, st))
+                ck(gemv_fused(self.act.data_ptr(), d, ow_d, h[r0:r0 + self.hs].data_ptr(), szp_d, self.h_loc.data_ptr(),
+                              self.hs, s.inter))
                 dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
                 h, h2 = h2, h
             else:
                 # silu(gate) * up is formed while down_proj stages its input
-                ck(lib.qeft_gemv_w4_silu(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), d.qweight.data_ptr(),
-                                         d.scales.data_ptr(), d.scaled_zeros.data_ptr(), ow_d, None, h.data_ptr(),
-                                         szp_d, h.data_ptr(), s.hidden, s.inter, g, no, st))
+                ck(gemv_silu(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), d.qweight.data_ptr(),
+                             d.scales.data_ptr(), d.scaled_zeros.data_ptr(), ow_d, None, h.data_ptr(),
+                             szp_d, h.data_ptr(), s.hidden, s.inter, g, no, st))
         if linears_only:
             return
         # an even number of buffer swaps per token: the result is back in hbuf[0]

@@ -188,3 +188,35 @@ def pack_oweight_device(oweights):
     with torch.cuda.device(ow.device):
         _lib.check(_lib.lib().qeft_pack_oweight(ow.data_ptr(), out.data_ptr(), n, r, _stream(ow)))
     return out
+
+
+# ---- 3-bit extension (include/qeft_hip.h, "3-bit EXTENSION"); the reference has no counterpart --------------------
+def gemv_3bit(x, qweight3, scales, scaled_zeros, oweight_il, bias, residual, m, n, k, group_size, sz_packed=None):
+    """y[m, n] = x . W3^T (+ bias, + residual) on the 3-bit stream; any m >= 1."""
+    _need(x.is_cuda and x.dtype == torch.float16, "x must be a Half GPU tensor (no CPU fallback)")
+    _need(qweight3.dtype == torch.int32 and qweight3.is_contiguous(), "qweight3 must be a contiguous Int tensor")
+    x = x.contiguous()
+    _need(x.numel() == m * k, f"x has {x.numel()} elements, expected m*k = {m * k}")
+    n_out = 0 if oweight_il is None else oweight_il.shape[1] // 2
+    _need(qweight3.shape == (n // 16, (k - n_out) // 128 * 192),
+          f"qweight3 shape {tuple(qweight3.shape)} != ({n // 16}, {(k - n_out) // 128 * 192})")
+    out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().qeft_gemv_w3(x.data_ptr(), qweight3.data_ptr(), scales.data_ptr(), scaled_zeros.data_ptr(),
+                                           oweight_il.data_ptr() if oweight_il is not None else None,
+                                           bias.data_ptr() if bias is not None else None,
+                                           residual.data_ptr() if residual is not None else None,
+                                           sz_packed.data_ptr() if sz_packed is not None else None, out.data_ptr(), m, n,
+                                           k, group_size, n_out, _stream(x)))
+    return out
+
+
+def expand_3bit(qweight3, n, k, n_out, out=None):
+    """3-bit stream -> int16 [n/4, k] in the 4-bit checkpoint layout (for the GEMM / backward / dequant kernels)."""
+    _need(qweight3.is_cuda and qweight3.dtype == torch.int32 and qweight3.is_contiguous(),
+          "qweight3 must be a contiguous Int GPU tensor")
+    if out is None:
+        out = torch.empty(n // 4, k, dtype=torch.int16, device=qweight3.device)
+    with torch.cuda.device(qweight3.device):
+        _lib.check(_lib.lib().qeft_expand_w3(qweight3.data_ptr(), out.data_ptr(), n, k, n_out, _stream(qweight3)))
+    return out

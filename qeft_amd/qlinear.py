@@ -68,6 +68,42 @@ def unpack_oweight(oweight_interleaved):
     return v.permute(0, 4, 1, 2, 3).reshape(n, r).contiguous()
 
 
+def pack_w3(q):
+    """int [N, Kq] in 0..7 -> int32 [N/16, (Kq/128)*192]: the 3-bit EXTENSION layout (the reference has none; spec and
+    closed form in oracle/qeft_oracle.py: pack_w3 / w3_position, C ABI notes in include/qeft_hip.h)."""
+    n, kq = q.shape
+    assert n % 16 == 0 and kq % 128 == 0
+    v = q.to(torch.int64).reshape(n // 16, 16, kq // 128, 4, 16, 2)      # rs, row, step, chunk, pair e, half h
+    words = torch.zeros(n // 16, 16, kq // 128, 4, 3, dtype=torch.int64, device=q.device)
+    for e in range(15):
+        for h in range(2):
+            words[..., e // 5] |= (v[..., e, h] & 7) << (16 * h + 3 * (e % 5))
+    for h in range(2):
+        for b in range(3):
+            words[..., b] |= ((v[..., 15, h] >> b) & 1) << (15 + 16 * h)
+    words = words.permute(0, 2, 3, 1, 4).reshape(n // 16, kq // 128 * 192)  # rs, step, chunk, row, i
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words)
+    return words.to(torch.int32).contiguous()
+
+
+def unpack_w3(qweight3):
+    """Inverse of pack_w3: int32 [N/16, S*192] -> uint8 [N, S*128]."""
+    nrs, cols = qweight3.shape
+    steps = cols // 192
+    w = (qweight3.to(torch.int64) & 0xFFFFFFFF).reshape(nrs, steps, 4, 16, 3).permute(0, 3, 1, 2, 4)
+    out = torch.zeros(nrs, 16, steps, 4, 16, 2, dtype=torch.int64, device=qweight3.device)
+    for e in range(15):
+        for h in range(2):
+            out[..., e, h] = (w[..., e // 5] >> (16 * h + 3 * (e % 5))) & 7
+    for h in range(2):
+        for b in range(3):
+            out[..., 15, h] |= ((w[..., b] >> (15 + 16 * h)) & 1) << b
+    return out.reshape(nrs * 16, steps * 128).to(torch.uint8)
+
+
+_W3_SCRATCH = {}   # device -> int16 scratch for the expanded 4-bit view of a 3-bit layer (inference, M > 16)
+
+
 # ----------------------------------------------------------------------------------------------------
 # autograd wrappers (reference QuantMatMulQEFT / QuantMatMul, qlinear.py:13-68)
 # ----------------------------------------------------------------------------------------------------
@@ -120,7 +156,8 @@ class QuantLinear(nn.Module):
 
     def __init__(self, bits, infeatures, outfeatures, bias, dtype, outlierfeatures, group_size, reorder, name):
         super().__init__()
-        assert bits in [4], "Only 4 bits is supported."
+        # the reference supports 4 bits only (qlinear.py:127); 3 is this build's extension (own layout, pack_w3)
+        assert bits in [3, 4], "Only 4 bits (reference layout) and 3 bits (extension layout) are supported."
         assert dtype == torch.float16, "Only fp16 is supported."
         self.bits = bits
         self.infeatures = infeatures
@@ -129,11 +166,17 @@ class QuantLinear(nn.Module):
         self.group_size = group_size if group_size != -1 else infeatures
         self.interleave = 4
         assert infeatures % self.group_size == 0
-        assert outfeatures % (32 // self.bits) == 0
-        int16_pack_num = 16 // self.bits
-
-        self.register_buffer("qweight", torch.empty(
-            (outfeatures // self.interleave, infeatures // int16_pack_num * self.interleave), dtype=torch.int16))
+        if bits == 3:
+            assert outfeatures % 16 == 0 and infeatures % 128 == 0 and outlierfeatures % 128 == 0 \
+                and outlierfeatures < infeatures and self.group_size in (128, infeatures), \
+                "3-bit layout: N % 16 == 0, K % 128 == 0, r % 128 == 0, group size 128 or K"
+            self.register_buffer("qweight", torch.empty(
+                (outfeatures // 16, (infeatures - outlierfeatures) // 128 * 192), dtype=torch.int32))
+        else:
+            assert outfeatures % (32 // self.bits) == 0
+            int16_pack_num = 16 // self.bits
+            self.register_buffer("qweight", torch.empty(
+                (outfeatures // self.interleave, infeatures // int16_pack_num * self.interleave), dtype=torch.int16))
         numgroup = infeatures // self.group_size
         self.register_buffer("scales", torch.empty((numgroup, outfeatures), dtype=dtype))
         self.register_buffer("scaled_zeros", torch.empty((numgroup, outfeatures), dtype=dtype))
@@ -171,7 +214,10 @@ class QuantLinear(nn.Module):
         if self.outlierfeatures > 0:
             cols = torch.arange(self.infeatures - self.outlierfeatures, self.infeatures)
             intweight[:, cols] = zeros[:, cols // self.group_size].to(torch.int32)   # dead nibbles hold z
-        self.qweight = pack_intweight(intweight, interleave=4, kstride=64)
+        if self.bits == 3:
+            self.qweight = pack_w3(intweight[:, :self.infeatures - self.outlierfeatures])
+        else:
+            self.qweight = pack_intweight(intweight, interleave=4, kstride=64)
         self.scales = scales.t().contiguous().to(dtype)
         self.scaled_zeros = -scale_zeros.t().contiguous().to(dtype)
         if self.outlierfeatures > 0:
@@ -196,8 +242,11 @@ class QuantLinear(nn.Module):
             self.forward = self.forward_outlier
             if "o_proj" in self.name or "out_proj" in self.name:
                 ids = sparse_to_dense_ids(self.outlieridx, self.infeatures)
-                self.register_buffer("reorder_ids", ids)
-                self.register_buffer("reorder_ids32", ids.to(torch.int32), persistent=False)
+                if "reorder_ids" in self._buffers:       # set_kernel() called again (e.g. switching to training)
+                    self.reorder_ids, self.reorder_ids32 = ids, ids.to(torch.int32)
+                else:
+                    self.register_buffer("reorder_ids", ids)
+                    self.register_buffer("reorder_ids32", ids.to(torch.int32), persistent=False)
                 self.forward = self.forward_outlier_out_proj
             if training:
                 self.matmul = QuantMatMulQEFT.apply
@@ -230,6 +279,38 @@ class QuantLinear(nn.Module):
                                                          self.infeatures, self.group_size)
         return szp
 
+    # ------------------------------------------------------------------ 3-bit extension
+    def _qweight4(self):
+        """The layer's weights in the 4-bit checkpoint layout (what the GEMM / backward kernels read).  Training keeps
+        one expanded copy per layer (autograd saves it for backward); inference expands into a per-device scratch."""
+        n, k, r = self.outfeatures, self.infeatures, self.outlierfeatures
+        if self.training:
+            c = getattr(self, "_qw4_cache", None)
+            if c is None or c.device != self.qweight.device:
+                c = self._qw4_cache = qeft_cuda.expand_3bit(self.qweight, n, k, r)
+            return c
+        dev = self.qweight.device
+        buf = _W3_SCRATCH.get(dev)
+        if buf is None or buf.numel() < n // 4 * k:
+            buf = _W3_SCRATCH[dev] = torch.empty(n // 4 * k, dtype=torch.int16, device=dev)
+        return qeft_cuda.expand_3bit(self.qweight, n, k, r, out=buf[:n // 4 * k].view(n // 4, k))
+
+    def _forward_w3(self, x, gather):
+        r = self.outlierfeatures
+        inputs = torch.index_select(x, -1, self.reorder_ids) if gather else x
+        if self.training:
+            if r > 0:
+                return self.matmul(inputs, self.oweight, self._qweight4(), self.scales, self.scaled_zeros, r, self.bias,
+                                   self.name)
+            return self.matmul(inputs, self._qweight4(), self.scales, self.scaled_zeros, r, self.bias, self.name)
+        seq_len = x.numel() // x.shape[-1]
+        if 0 < seq_len <= 16:   # decode / few rows: the 3-bit stream is read directly
+            return qeft_cuda.gemv_3bit(inputs, self.qweight, self.scales, self.scaled_zeros,
+                                       self.oweight_interleaved if r > 0 else None, self.bias, None, seq_len,
+                                       self.outfeatures, self.infeatures, self.group_size, self._szp(x))
+        return qeft_cuda.gemm_4bit_qeft(inputs, self._qweight4(), self.scales, self.scaled_zeros,
+                                        self._outlier_weight_f16() if r > 0 else None, self.bias)
+
     # ------------------------------------------------------------------ forwards (qlinear.py:244-330)
     def _outlier_weight_f16(self):
         ow = self.oweight
@@ -238,6 +319,8 @@ class QuantLinear(nn.Module):
         return ow[:, -self.outlierfeatures:].contiguous() if ow.shape[1] != self.outlierfeatures else ow
 
     def forward_outlier(self, x):
+        if self.bits == 3:
+            return self._forward_w3(x, False)
         if self.training:
             return self.matmul(x, self.oweight, self.qweight, self.scales, self.scaled_zeros,
                                self.outlierfeatures, self.bias, self.name)
@@ -258,6 +341,8 @@ class QuantLinear(nn.Module):
         return y + self.bias if self.bias is not None else y
 
     def forward_outlier_out_proj(self, x):
+        if self.bits == 3:
+            return self._forward_w3(x, True)
         if self.training:
             inputs = torch.index_select(x, -1, self.reorder_ids)
             return self.matmul(inputs, self.oweight, self.qweight, self.scales, self.scaled_zeros,
@@ -281,6 +366,8 @@ class QuantLinear(nn.Module):
         return y + self.bias if self.bias is not None else y
 
     def forward_normal(self, x):
+        if self.bits == 3:
+            return self._forward_w3(x, False)
         if self.training:
             return self.matmul(x, self.qweight, self.scales, self.scaled_zeros, self.outlierfeatures, self.bias,
                                self.name)

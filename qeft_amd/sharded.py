@@ -12,18 +12,20 @@ import torch.nn as nn
 from .qlinear import QuantLinear
 
 
-def shard_bounds(n, rank, world):
-    assert n % (8 * world) == 0, f"out_features {n} must be a multiple of 8*world_size ({8 * world})"
+def shard_bounds(n, rank, world, align=8):
+    """Rows of rank `rank`; `align` = 8 keeps both 4-bit interleaves, 16 the row sets of the 3-bit layout."""
+    assert n % (align * world) == 0, f"out_features {n} must be a multiple of {align}*world_size ({align * world})"
     per = n // world
     return rank * per, (rank + 1) * per
 
 
 def shard_quantlinear(ql: QuantLinear, rank: int, world: int) -> QuantLinear:
     """Rows [n0, n1) of a packed QuantLinear as a stand-alone QuantLinear (shares no storage with the original)."""
-    n0, n1 = shard_bounds(ql.outfeatures, rank, world)
+    n0, n1 = shard_bounds(ql.outfeatures, rank, world, 16 if ql.bits == 3 else 8)
     out = QuantLinear(ql.bits, ql.infeatures, n1 - n0, ql.bias is not None, ql.dtype, ql.outlierfeatures,
                       ql.group_size, getattr(ql, "reorder", False), ql.name)
-    out.qweight = ql.qweight[n0 // 4:n1 // 4].clone()
+    rows = 16 if ql.bits == 3 else 4      # weight rows per qweight row
+    out.qweight = ql.qweight[n0 // rows:n1 // rows].clone()
     out.scales = ql.scales[:, n0:n1].contiguous()
     out.scaled_zeros = ql.scaled_zeros[:, n0:n1].contiguous()
     if ql.bias is not None:

@@ -47,8 +47,12 @@ def test_quantlinear_pack_state_dict_matches_reference(path):
 
 
 def test_constructor_contract():
-    with pytest.raises(AssertionError, match="Only 4 bits"):
+    with pytest.raises(AssertionError, match="Only 4 bits"):     # the reference: bits in [4] (qlinear.py:127)
+        QuantLinear(2, 128, 8, False, torch.float16, 0, 128, False, "x")
+    with pytest.raises(AssertionError, match="3-bit layout"):    # 3 bits is the extension: own shape rules
         QuantLinear(3, 128, 8, False, torch.float16, 0, 128, False, "x")
+    q3 = QuantLinear(3, 512, 64, False, torch.float16, 128, 128, True, "model.layers.0.mlp.up_proj")
+    assert q3.qweight.shape == (4, 3 * 192) and q3.qweight.dtype == torch.int32
     with pytest.raises(AssertionError, match="Only fp16"):
         QuantLinear(4, 128, 8, False, torch.bfloat16, 0, 128, False, "x")
     ql = QuantLinear(4, 4096, 4096, False, torch.float16, 128, 128, True, "model.layers.0.self_attn.q_proj")
