@@ -165,6 +165,29 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel (4 launches per layer)",
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3)}
+        # the same, one GEMV of the layer at a time (32 launches per replay): per-kernel rates for DESIGN.md / rocprof
+        if g2 is not None and world == 1:
+            per = {}
+            lin0 = eng.lin[0]
+            parts = {"qkv": ("q", "k", "v"), "o": ("o",), "gu": ("g", "u"), "d": ("d",)}
+            for tag, names in parts.items():
+                gk = eng.capture(linears_only=True, only=tag)
+                for _ in range(3):
+                    gk.replay()
+                torch.cuda.synchronize(dev)
+                e0.record(torch.cuda.current_stream(dev))
+                for _ in range(reps):
+                    gk.replay()
+                e1.record(torch.cuda.current_stream(dev))
+                torch.cuda.synchronize(dev)
+                us = e0.elapsed_time(e1) * 1e3 / (reps * shape.n_layers)
+                nbytes = 0
+                for nm in names:
+                    l = lin0[nm]
+                    n_, k_, r_, g_ = l.outfeatures, l.infeatures, l.outlierfeatures, l.group_size
+                    nbytes += n_ * (k_ - r_) * l.bits // 8 + 2 * (k_ // g_) * n_ * 2 + n_ * r_ * 2 + 2 * k_ + 2 * n_
+                per[tag] = {"us": round(us, 2), "bytes": int(nbytes), "GB/s": round(nbytes / us / 1e3, 1)}
+            roof["per_launch_kind"] = per
     except Exception as e:  # never lose the headline number because of the side measurement
         if rank == 0:
             print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)

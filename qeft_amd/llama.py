@@ -310,7 +310,8 @@ class DecodeEngine:
 
     # -- the launch sequence ---------------------------------------------------------------------------
     @torch.no_grad()
-    def _launch_token(self, linears_only=False):
+    def _launch_token(self, linears_only=False, only=None):
+        """only (with linears_only): launch just one GEMV of every layer -- "qkv", "o", "gu" or "d" -- for per-kernel timing."""
         import torch.distributed as dist
         s, lib, ck, P, tp = self.m.shape, self.lib, _lib.check, self.P, self.tp
         w3 = self.bits == 3
@@ -324,6 +325,11 @@ class DecodeEngine:
                                         None, residual, szp, y, 1, n, k, g, no, st)
             return lib.qeft_gemv_w4_fused(x, ql.qweight.data_ptr(), ql.scales.data_ptr(), ql.scaled_zeros.data_ptr(), ow,
                                           None, None, residual, szp, y, 1, n, k, g, no, st)
+
+        def pick(tag, fn):      # per-kernel timing (bench.py): keep one GEMV of the layer, drop the others
+            return fn if only in (None, tag) else (lambda *a: 0)
+        group_qkv, group_gu = pick("qkv", gemv_group), pick("gu", gemv_group)
+        fused_o, fused_d, silu_d = pick("o", gemv_fused), pick("d", gemv_fused), pick("d", gemv_silu)
 
         st = torch.cuda.current_stream(self.dev).cuda_stream
         h, h2 = self.hbuf
@@ -339,8 +345,8 @@ class DecodeEngine:
             lin, pk = self.lin[li], self.packs[li]
             # input_layernorm is fused into the q|k|v launch (x is normalised while it is staged)
             qw, sc, sz, ow, ys, ns, szp = pk["qkv"]
-            ck(gemv_group(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
-                          s.hidden, g, no, st))
+            ck(group_qkv(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
+                         s.hidden, g, no, st))
             if tp:
                 dist.all_gather_into_tensor(self.qkv_all.view(-1), self.qkv_loc, group=self.tp_group)
                 self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
@@ -358,15 +364,15 @@ class DecodeEngine:
             szp_o = o._szp(o.scales)
             szp_o = szp_o.data_ptr() if szp_o is not None else None
             if tp:
-                ck(gemv_fused(self.att.data_ptr(), o, ow_o, h[r0:r0 + self.hs].data_ptr(), szp_o, self.h_loc.data_ptr(),
-                              self.hs, s.hidden))
+                ck(fused_o(self.att.data_ptr(), o, ow_o, h[r0:r0 + self.hs].data_ptr(), szp_o, self.h_loc.data_ptr(),
+                           self.hs, s.hidden))
                 dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
                 h, h2 = h2, h
             else:
-                ck(gemv_fused(self.att.data_ptr(), o, ow_o, h.data_ptr(), szp_o, h.data_ptr(), s.hidden, s.hidden))
+                ck(fused_o(self.att.data_ptr(), o, ow_o, h.data_ptr(), szp_o, h.data_ptr(), s.hidden, s.hidden))
             qw, sc, sz, ow, ys, ns, szp = pk["gu"]
-            ck(gemv_group(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz, ow, None, szp,
-                          ys, ns, s.hidden, g, no, st))
+            ck(group_gu(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz, ow, None, szp,
+                        ys, ns, s.hidden, g, no, st))
             if tp:
                 if not linears_only:
                     ck(lib.qeft_silu_mul(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), self.act_loc.data_ptr(),
@@ -377,15 +383,15 @@ class DecodeEngine:
             szp_d = d._szp(d.scales)
             szp_d = szp_d.data_ptr() if szp_d is not None else None
             if tp:
-                ck(gemv_fused(self.act.data_ptr(), d, ow_d, h[r0:r0 + self.hs].data_ptr(), szp_d, self.h_loc.data_ptr(),
-                              self.hs, s.inter))
+                ck(fused_d(self.act.data_ptr(), d, ow_d, h[r0:r0 + self.hs].data_ptr(), szp_d, self.h_loc.data_ptr(),
+                           self.hs, s.inter))
                 dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
                 h, h2 = h2, h
             else:
                 # silu(gate) * up is formed while down_proj stages its input
-                ck(gemv_silu(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), d.qweight.data_ptr(),
-                             d.scales.data_ptr(), d.scaled_zeros.data_ptr(), ow_d, None, h.data_ptr(),
-                             szp_d, h.data_ptr(), s.hidden, s.inter, g, no, st))
+                ck(silu_d(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), d.qweight.data_ptr(),
+                          d.scales.data_ptr(), d.scaled_zeros.data_ptr(), ow_d, None, h.data_ptr(),
+                          szp_d, h.data_ptr(), s.hidden, s.inter, g, no, st))
         if linears_only:
             return
         # an even number of buffer swaps per token: the result is back in hbuf[0]
@@ -395,20 +401,20 @@ class DecodeEngine:
         ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
                               1 if self.greedy else 0, st))
 
-    def capture(self, linears_only=False):
+    def capture(self, linears_only=False, only=None):
         """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires)."""
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         pos0, tok0 = self.pos.clone(), self.tok.clone()
         with torch.cuda.stream(side):
-            self._launch_token(linears_only)
+            self._launch_token(linears_only, only)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         self.pos.copy_(pos0)
         self.tok.copy_(tok0)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._launch_token(linears_only)
+            self._launch_token(linears_only, only)
         self.pos.copy_(pos0)
         self.tok.copy_(tok0)
         if linears_only:
