@@ -82,6 +82,16 @@ int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const v
                  const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size,
                  int n_out, qeft_stream_t stream);
 
+/* The same with a scratch buffer for mid-size m: when the 128x128 tiling of [m, n] leaves most of the chip idle the
+ * K loop is cut into S parts (fp32 partial tiles in `workspace`, summed in a fixed order by a second small launch --
+ * deterministic).  qeft_gemm_w4_workspace_bytes() is the size that enables it for a shape (0: no split would be
+ * used); a smaller or NULL workspace silently means fewer parts / none.  16-byte aligned device memory, contents
+ * irrelevant, must not be shared by launches that may overlap. */
+long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out);
+int qeft_gemm_w4_ws(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                    const void* oweight, const void* bias, void* y, void* workspace, long long workspace_bytes, int m,
+                    int n, int k, int group_size, int n_out, qeft_stream_t stream);
+
 /* Backward wrt the input: dx[M,K] = dy[M,N] . Wdeq[N,K]; columns K-n_out.. use oweight (SURVEY.md §8a row 7;
  * the mathematically correct form of QuantMatMulQEFT.backward, qlinear.py:30-44). */
 int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,

@@ -30,7 +30,9 @@ hipError_t dequant_w4_launch(const void* qw, const void* scales, const void* zer
 hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream_t st);
 hipError_t pack_scales_launch(const void* scales, const void* zeros, void* out, int N, int ngroups, hipStream_t st);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
-                          const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st);
+                          const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
+                          void* workspace = nullptr, size_t workspace_bytes = 0);
+int gemm_w4_split(int M, int N, int K, int n_out);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st);
 hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, int N, int K, int n_out,
@@ -42,8 +44,11 @@ static thread_local int g_last_hip_error = 0;
 // Measured crossover (tools/bench_gemm.py): one 16-row slice costs ~13 us per 2^24 weights, the
 // GEMM at M <= 128 is latency-bound at ~54 us per 4096 of K whatever N is -> the GEMV route wins while
 // slices * N <= 16384 (always for one slice).
-static bool small_m_route(int m, int n) {
+// With a split-K workspace (qeft_gemm_w4_ws) the GEMM itself is no longer latency-bound at these sizes (M = 128:
+// 24 / 31 / 46 us on the three Llama-2-7B shapes) and wins from the second slice on.
+static bool small_m_route(int m, int n, bool have_workspace = false) {
     if (m <= 16) return true;
+    if (have_workspace) return false;
     const int slices = (m + 15) / 16;
     return m <= 64 && (long long)slices * n <= 16384;
 }
@@ -143,15 +148,15 @@ int qeft_gemv_w4_qeft(const void* x, const void* qweight, const void* scales, co
                            group_size, n_out, stream);
 }
 
-int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
-                 const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size, int n_out,
-                 qeft_stream_t stream) {
+static int gemm_impl(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                     const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size, int n_out,
+                     qeft_stream_t stream, void* workspace, size_t workspace_bytes) {
     if (m < 1) return QEFT_ERR_SHAPE;
     if (!oweight) n_out = 0;
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
-    if (small_m_route(m, n) && (n_out > 0) == (oweight != nullptr)) {
+    if (small_m_route(m, n, workspace != nullptr && workspace_bytes > 0) && (n_out > 0) == (oweight != nullptr)) {
         // few rows: stream the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
         // (gemm_4bit semantics with oweight == NULL and a non-zero slice -- dead nibbles -- stays on the GEMM kernel.)
         qeft::GemvArgs a{};
@@ -174,7 +179,27 @@ int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const v
         if (e != hipErrorNotSupported) return finish(e);
     }
     return finish(qeft::gemm_w4_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out,
-                                       (hipStream_t)stream));
+                                       (hipStream_t)stream, workspace, workspace_bytes));
+}
+
+int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                 const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size, int n_out,
+                 qeft_stream_t stream) {
+    return gemm_impl(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out, stream, nullptr, 0);
+}
+
+long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {
+    if (m < 1 || n < 1 || k < 1 || n_out < 0 || n_out >= k || small_m_route(m, n, true)) return 0;
+    const int s = qeft::gemm_w4_split(m, n, k, n_out);
+    return s > 1 ? (long long)s * m * n * 4 : 0;
+}
+
+int qeft_gemm_w4_ws(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                    const void* oweight, const void* bias, void* y, void* workspace, long long workspace_bytes, int m,
+                    int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    if (workspace && !aligned16(workspace)) return QEFT_ERR_ALIGN;
+    return gemm_impl(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out, stream, workspace,
+                     workspace && workspace_bytes > 0 ? (size_t)workspace_bytes : 0);
 }
 
 int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,

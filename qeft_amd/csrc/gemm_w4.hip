@@ -222,7 +222,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
                                                                   const f16* __restrict__ zeros,
                                                                   const f16* __restrict__ ow, const f16* __restrict__ bias,
                                                                   f16* __restrict__ y, int M, int N, int K, int G,
-                                                                  int n_out) {
+                                                                  int n_out, float* __restrict__ part) {
+    // Split-K (gridDim.z = S > 1, mid-size M: too few 128x128 tiles to fill the chip and a K loop that is bound by
+    // request latency): block z contracts its share of the INT4 k-tiles (the last one also the fp16 tiles) and writes
+    // an fp32 partial tile to part[z][M][N]; gemm_splitk_reduce_kernel sums the S partials in order, adds the bias
+    // and rounds once.
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];     // [kStages][A 16 KB | B 4 KB] [sz]
     uint32_t* szl = (uint32_t*)(lds + kStages * kTileBytes);          // [K/G][128]
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;                   // LDS byte address of the array (for the asm reads)
@@ -234,6 +238,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     const int ktiles = K / BK;
     const int kq = K - (OUTL ? n_out : 0);
     const int qtiles = kq / BK;            // INT4 k-tiles [0, qtiles); outlier k-tiles [qtiles, ktiles) (n_out % 64 == 0)
+    const int S = gridDim.z, z = blockIdx.z;
+    const int kt0 = (int)((long long)qtiles * z / S), kt1 = (int)((long long)qtiles * (z + 1) / S);   // this block's INT4 tiles
     const int ngroups = K / G;
     const int gshift = 31 - __builtin_clz(G);    // G is a power of two on this path (checked by the launcher)
 
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     __syncthreads();   // scale words visible to every wave; no DMA is in flight yet, so the implied vmcnt(0) is free
 #pragma unroll
     for (int t = 0; t < kStages - 1; ++t)
-        if (t < ktiles) stage(t);
+        if (kt0 + t < kt1) stage(kt0 + t);
 
     auto mma_tile = [&](uint32_t tbase, const u32x4 (&bfrag)[4], u32x4 (&a0)[4]) {
         u32x4 a1[4];
@@ -308,11 +314,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     };
 
     // ---- main loop over the INT4 k-tiles: kStages-1 tiles in flight, one barrier per tile
-    for (int t = 0; t < qtiles; ++t) {
-        const int younger = min(qtiles - 1 - t, kStages - 2);
+    for (int t = kt0; t < kt1; ++t) {
+        const int younger = min(kt1 - 1 - t, kStages - 2);
         wait_vm(younger * 5);
         __builtin_amdgcn_s_barrier();      // every wave's DMA for tile t landed; everyone is done reading tile t-1
-        if (t + kStages - 1 < qtiles) stage(t + kStages - 1);   // overwrites the buffer of tile t-1
+        if (t + kStages - 1 < kt1) stage(t + kStages - 1);   // overwrites the buffer of tile t-1
 
         const uint32_t tbase = lds0 + (uint32_t)(t % kStages) * kTileBytes;
         const u32x4 q = lds_read16(tbase + boff);
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     }
 
     // ---- fp16 outlier k-tiles (2 for r = 128): pipeline is empty; A by DMA, B fragments straight from oweight
-    if (OUTL) {
+    if (OUTL && z == S - 1) {
         for (int t = qtiles; t < ktiles; ++t) {
             __builtin_amdgcn_s_barrier();          // all waves finished reading the buffers of earlier tiles
             uint8_t* base = lds;                   // stage buffer 0
@@ -361,7 +367,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
         }
     }
 
-    if (nok) {
+    if (nok && S > 1) {
+        float* pz = part + (size_t)z * M * N;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M) pz[(size_t)m * N + ncol] = acc[mt][e];
+            }
+    } else if (nok) {
         const float bv = bias ? (float)bias[ncol] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -373,9 +388,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     }
 }
 
+// y[m][n] = fp16(sum_z part[z][m][n] + bias[n]); 4 outputs per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, const f16* __restrict__ bias,
+                                                                 f16* __restrict__ y, int M, int N, int S) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t total = (size_t)M * N;
+    if (i >= total) return;
+    f32x4 acc = *(const f32x4*)(part + i);
+    for (int zz = 1; zz < S; ++zz) acc += *(const f32x4*)(part + (size_t)zz * total + i);
+    const int n = (int)(i % N);
+    h4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (f16)(acc[j] + (bias ? (float)bias[n + j] : 0.f));
+    *(h4*)(y + i) = o;
+}
+
+// Split factor for a shape: 1 unless the 128x128 tiling leaves most of the 256 CUs idle and K is long enough to cut.
+int gemm_w4_split(int M, int N, int K, int n_out) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int qtiles = (K - n_out) / BK;
+    if (tiles >= 256 || qtiles < 16) return 1;
+    int s = 512 / tiles;               // aim at ~2 blocks per CU
+    if (s > qtiles / 8) s = qtiles / 8; // every split keeps >= 8 k-tiles: the DMA ring needs a few to pay off
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
-                          const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st) {
+                          const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
+                          void* workspace, size_t workspace_bytes) {
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
+    int S = workspace ? gemm_w4_split(M, N, K, (ow && n_out > 0) ? n_out : 0) : 1;
+    while (S > 1 && (size_t)S * M * N * 4 > workspace_bytes) --S;
+    if (N % 4 != 0) S = 1;
     const bool outl = ow && n_out > 0;
     const size_t smem2 = gemm_v2_smem(K, G);
     if (K / BK >= kStages && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && smem2 <= 160 * 1024 &&
@@ -384,14 +429,21 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             auto kern = gemm_w4_kernel_v2<true>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw, (const f16*)scales,
-                               (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G, n_out);
+            hipLaunchKernelGGL(kern, dim3(grid.x, grid.y, S), dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw,
+                               (const f16*)scales, (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G,
+                               n_out, (float*)workspace);
         } else {
             auto kern = gemm_w4_kernel_v2<false>;
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw, (const f16*)scales,
-                               (const f16*)zeros, (const f16*)nullptr, (const f16*)bias, (f16*)y, M, N, K, G, 0);
+            hipLaunchKernelGGL(kern, dim3(grid.x, grid.y, S), dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw,
+                               (const f16*)scales, (const f16*)zeros, (const f16*)nullptr, (const f16*)bias, (f16*)y, M, N, K, G,
+                               0, (float*)workspace);
+        }
+        if (S > 1) {
+            const size_t quads = (size_t)M * N / 4;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, st,
+                               (const float*)workspace, (const f16*)bias, (f16*)y, M, N, S);
         }
         return hipGetLastError();
     }

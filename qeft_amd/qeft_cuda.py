@@ -87,11 +87,29 @@ def gemm_4bit_qeft(in_feats, kernel, scales, zeros, oweights, bias=None):
     if m == 0:
         return out
     with torch.cuda.device(in_feats.device):
-        _lib.check(_lib.lib().qeft_gemm_w4(x.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+        lib = _lib.lib()
+        st = _stream(x)
+        need = lib.qeft_gemm_w4_workspace_bytes(m, n, k, n_out)
+        if need > 0:
+            # mid-size m: split-K through a scratch buffer (one per device and stream: launches that share it are
+            # ordered by that stream)
+            key = (x.device.index, st)
+            ws = _GEMM_WS.get(key)
+            if ws is None or ws.numel() * 4 < need:
+                ws = _GEMM_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+            _lib.check(lib.qeft_gemm_w4_ws(x.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
                                            oweights.data_ptr() if n_out else None,
-                                           bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k,
-                                           group, n_out, _stream(x)))
+                                           bias.data_ptr() if bias is not None else None, out.data_ptr(), ws.data_ptr(),
+                                           ws.numel() * 4, m, n, k, group, n_out, st))
+        else:
+            _lib.check(lib.qeft_gemm_w4(x.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                        oweights.data_ptr() if n_out else None,
+                                        bias.data_ptr() if bias is not None else None, out.data_ptr(), m, n, k,
+                                        group, n_out, st))
     return out
+
+
+_GEMM_WS = {}   # (device index, stream) -> fp32 scratch of the split-K GEMM
 
 
 # ---- entry points beyond the reference's module (used by QuantLinear's fused paths and the backward) ----

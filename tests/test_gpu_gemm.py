@@ -105,3 +105,36 @@ def test_pack_oweight_device_bit_exact():
     got = qeft_cuda.pack_oweight_device(torch.from_numpy(ow).to(DEV))
     torch.cuda.synchronize()
     assert np.array_equal(got.cpu().numpy().view(np.uint16), O.pack_oweight(ow).view(np.uint16))
+
+
+@pytest.mark.parametrize("m,n,k,r", [(200, 512, 4096, 128), (130, 256, 2048, 0), (520, 1024, 11008, 128)])
+def test_gemm_split_k_path_vs_oracle(m, n, k, r):
+    """Mid-size M: the K loop is cut into S parts through an fp32 workspace and summed in a fixed order."""
+    from qeft_amd import _lib, qeft_cuda
+    lib, g = _lib.lib(), 128
+    need = lib.qeft_gemm_w4_workspace_bytes(m, n, k, r)
+    assert need >= 2 * m * n * 4, "shape chosen so that the split path is taken"
+    assert lib.qeft_gemm_w4_workspace_bytes(4096, 4096, 4096, 128) == 0      # enough tiles: no split
+    assert lib.qeft_gemm_w4_workspace_bytes(8, 4096, 4096, 128) == 0         # few rows: the GEMV route
+    bufs = O.make_layer(n, k, r, g, seed=m)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=3)
+    xt = torch.from_numpy(x).to(DEV)
+    bias = torch.randn(n, device=DEV).half()
+    y = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight"), bias)
+    y2 = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight"), bias)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)                                                  # fixed summation order
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight"),
+                          bias.cpu().numpy(), g)
+    assert rel_err(y.cpu().numpy(), yref) < REL_TOL
+    # a workspace that only fits 2 parts, and none at all: same result within tolerance (other summation order)
+    out = torch.empty_like(y)
+    ws = torch.empty(2 * m * n, dtype=torch.float32, device=DEV)
+    for wsp, nbytes in ((ws.data_ptr(), ws.numel() * 4), (None, 0)):
+        _lib.check(lib.qeft_gemm_w4_ws(xt.data_ptr(), t["qweight"].data_ptr(), t["scales"].data_ptr(),
+                                       t["scaled_zeros"].data_ptr(), t["oweight"].data_ptr() if r else None,
+                                       bias.data_ptr(), out.data_ptr(), wsp, nbytes, m, n, k, g, r,
+                                       torch.cuda.current_stream(DEV).cuda_stream))
+        torch.cuda.synchronize()
+        assert rel_err(out.cpu().numpy(), yref) < REL_TOL
