@@ -101,11 +101,20 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     (void)xst;
     (void)ast;
     if (!XG) {
+        {
+            const size_t e = (size_t)min(tid, xvecs - 1) * 8;
+            xst[0] = *(const u32x4*)(a.x + e);
+            if (XT) ast[0] = *(const u32x4*)(a.xt_aux + e);
+        }
+        // rows longer than one pass (K > 4096 at batch 1): ONE block-uniform region whose registers are undefined on
+        // the other path (nothing to merge at the join, hence no wait there -- checked with tools/isa_waits.py)
+        if (xvecs > kBlock) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
-            xst[p] = *(const u32x4*)(a.x + e);
-            if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
+            for (int p = 1; p < 4; ++p) {
+                const size_t e = (size_t)min(p * kBlock + tid, xvecs - 1) * 8;
+                xst[p] = *(const u32x4*)(a.x + e);
+                if (XT) ast[p] = *(const u32x4*)(a.xt_aux + e);
+            }
         }
     }
     const int slab_vecs = OUTL ? RS * 8 * (2 * a.n_out) / 8 : 0;      // 8 interleaved rows of 2*n_out halves per row set
@@ -171,15 +180,16 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         // staging barrier any more (it cost ~0.8 us per launch).
         float ss = 0.f;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float sp = 0.f;
+        for (int p = 0; p < 4; ++p)
+            if (p == 0 || p * kBlock < xvecs) {            // block-uniform and registers only: whole passes are skipped
+                float sp = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const h2 t = as_h2(xst[p][j]);
-                sp += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
+                for (int j = 0; j < 4; ++j) {
+                    const h2 t = as_h2(xst[p][j]);
+                    sp += (float)t[0] * (float)t[0] + (float)t[1] * (float)t[1];
+                }
+                ss += (p * kBlock + tid < xvecs) ? sp : 0.f;   // the tail of a partial pass re-read the last vector
             }
-            ss += (p * kBlock + tid < xvecs) ? sp : 0.f;   // passes beyond the row re-read the last vector
-        }
         mark(6);
         ss = row16_sum(ss);
         ss += __shfl_xor(ss, 16);
@@ -206,10 +216,11 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     mark(7);
     // ---- 3. stage scales, x' (+ per-step sums) and the outlier slab into LDS
     if (a.sz_blk) {
+        // shadow is [rs][group][16] dwords, LDS [rs][nsteps][16]: the same thing unless the layer is per-channel
         for (int v = tid; v < szvecs; v += kBlock) {
             const u32x4 t = (v == tid) ? szv[0] : (v == tid + kBlock) ? szv[1] : *(const u32x4*)(szsrc + (size_t)v * 4);
-            const int rs = v / (ngroups * 4), rem = v % (ngroups * 4);     // shadow is [rs][group][16]; LDS is [rs][nsteps][16]
-            *(u32x4*)(szl + (rs * nsteps + (rem >> 2)) * 16 + (rem & 3) * 4) = t;
+            const int dst = per_channel ? ((v >> 2) * nsteps * 16 + (v & 3) * 4) : v * 4;
+            *(u32x4*)(szl + dst) = t;
         }
     } else
     for (int i = tid, p = 0; i < szn; i += kBlock, ++p) {
@@ -230,7 +241,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         for (int v = tid, p = 0; v < xvecs; v += kBlock, ++p) {
             u32x4 xv;
             const int e = v * 8;
-            const int bm = e / a.K, k = e - bm * a.K;
+            const int bm = (M == 1) ? 0 : e / a.K, k = e - bm * a.K;
             if (XG) {
                 f16 t[8];
 #pragma unroll
@@ -301,7 +312,9 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         for (int v = tid; v < slab_vecs; v += kBlock) {
             const u32x4 ov = (v == tid) ? ost[0] : (v == tid + kBlock) ? ost[1] : *(const u32x4*)(osrc + (size_t)v * 8);
             const int per_row = (2 * a.n_out) / 8;
-            const int ir = v / per_row, piece = v % per_row;
+            int ir, piece;
+            if (a.n_out == 128) { ir = v >> 5; piece = v & 31; }       // the checkpoint's r: no integer division
+            else { ir = v / per_row; piece = v % per_row; }
             const int d0 = (piece >> 3) * 16 + (piece & 7) * 2;          // natural dwords d0, d0+1 of the row
             const u32x2 lo = {__builtin_amdgcn_perm(ov[1], ov[0], 0x05040100u), __builtin_amdgcn_perm(ov[3], ov[2], 0x05040100u)};
             const u32x2 hi = {__builtin_amdgcn_perm(ov[1], ov[0], 0x07060302u), __builtin_amdgcn_perm(ov[3], ov[2], 0x07060302u)};

@@ -165,6 +165,8 @@ int main(int argc, char** argv) {
         printf("N=%d K=%d algorithmic bytes %.0f\n", N, K, bytes);
         const int nb = N / 16 < 512 ? N / 16 : 256 * ((N / 16 + 384) / 768);
         run_mfma<8, 4, 0, 1>("mfma +rmsnorm D=4", Ls, x, y, N, K, bytes, nb);
+        timeline<8, 4, 1>(Ls, x, y, N, K, nb);
+        timeline<8, 4, 0>(Ls, x, y, N, K, nb);
         run_mfma<8, 4, 0, 0>("mfma plain D=4", Ls, x, y, N, K, bytes, nb);
         run_mfma<8, 4, 0, 2>("mfma silu*up D=4", Ls, x, y, N, K, bytes, nb);
         for (auto& l : Ls) { (void)hipFree(l.qw); (void)hipFree(l.sc); (void)hipFree(l.sz); (void)hipFree(l.ow); }
