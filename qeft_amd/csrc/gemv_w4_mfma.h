@@ -152,9 +152,11 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     typedef typename std::conditional<BITS == 3, u32x3_u, u32x4>::type ring_t;
     ring_t ring[D];
     const uint32_t step_bytes = BITS == 3 ? 768u : 256u;
-    const uint8_t* wbase = BITS == 3
-        ? a.qw + (size_t)set0 * nfull * 768u + lane * 12
-        : a.qw + (size_t)(rg0 + (nl >> 2)) * a.K * 2 + (kc >> 1) * 128 + (nl & 3) * 32 + (kc & 1) * 16;
+    // address = wave-uniform base (scalar registers) + a 32-bit per-lane offset: the load takes the `saddr + voffset`
+    // form and a step costs two scalar adds instead of a 64-bit vector multiply-add
+    const uint8_t* wbase = BITS == 3 ? a.qw + (size_t)set0 * nfull * 768u : a.qw + (size_t)rg0 * a.K * 2;
+    const uint32_t lane_off = BITS == 3 ? (uint32_t)lane * 12u
+                                        : (uint32_t)(nl >> 2) * (uint32_t)a.K * 2u + (kc >> 1) * 128 + (nl & 3) * 32 + (kc & 1) * 16;
     const uint32_t rs_bytes = BITS == 3 ? (uint32_t)nfull * 768u : (uint32_t)a.K * 8u;   // bytes per row set
     const uint32_t last_off = BITS == 3 ? (uint32_t)max(nfull - 1, 0) * 768u : (uint32_t)a.K * 2 - 256u;
     int p_rs = 0, p_i = 0;                                             // (row set, index) of the next step to issue
@@ -162,7 +164,8 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         // past the end (or a wave without ring steps): harmless re-read of a valid address inside the row set
         const int irs = min(p_rs, RS - 1);
         const uint32_t woff = min((uint32_t)(wave + p_i * kWaves) * step_bytes, last_off);
-        b = __builtin_nontemporal_load((const ring_t*)(wbase + (size_t)irs * rs_bytes + woff));
+        const uint8_t* sp = wbase + ((size_t)irs * rs_bytes + woff);     // wave-uniform
+        b = __builtin_nontemporal_load((const ring_t*)(sp + lane_off));
         if (++p_i >= nsw) { p_i = 0; ++p_rs; }
     };
 #pragma unroll
@@ -335,7 +338,10 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     mark(2);
 
     // ---- 4. steps
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};     // acc[j]: batch row m = 4*kc + j, weight row nl of the current row set
+    constexpr int NACC = M < 4 ? M : 4;   // batch rows a lane can own: m = 4*kc + j (rows >= M are never stored)
+    float acc[NACC];                      // acc[j]: batch row m = 4*kc + j, weight row nl of the current row set
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
     uint32_t MAGIC = 0x64006400u;
     asm volatile("" : "+v"(MAGIC));
     const int am = min(nl, MR - 1);         // A-operand row of this lane (rows >= M replicate row M-1, never stored)
@@ -350,16 +356,19 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             f32x4 P = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) P = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[w], pw[w], P, 0, 0, 0);
-            if (!(ABL & 4)) acc += P;
+            if (!(ABL & 4)) {
+#pragma unroll
+                for (int j = 0; j < NACC; ++j) acc[j] += P[j];
+            }
         }
     };
     auto flush = [&](int rs) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NACC; ++j) {
             const int m = 4 * kc + j;
             if (m < MR) red[((rs * kWaves + wave) * MR + m) * 16 + nl] = acc[j];
+            acc[j] = 0.f;
         }
-        acc = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
     // LDS operands of a step (A fragments, the row's scale word, the step's correction sums) are fetched one step
@@ -367,7 +376,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
     struct StepOps {
         h8v x[4];
         uint32_t szw;
-        float2 ab[M < 4 ? M : 4];
+        float2 ab[NACC];
     };
     int c_rs = 0, c_i = 0;                 // (row set, index) of the next step to consume
     auto fetch_ops = [&](StepOps& o) {
@@ -378,7 +387,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
         for (int w = 0; w < 4; ++w) o.x[w] = px[w];
         o.szw = szl[(rs * nsteps + (per_channel ? 0 : s)) * 16 + nl];
 #pragma unroll
-        for (int j = 0; j < (M < 4 ? M : 4); ++j) {       // batch row m = 4*kc + j; rows >= M are never stored
+        for (int j = 0; j < NACC; ++j) {                  // batch row m = 4*kc + j; rows >= M are never stored
             const int m = min(4 * kc + j, MR - 1);
             o.ab[j] = *(const float2*)(corr + ((size_t)m * nsteps + s) * 2);
         }
@@ -432,7 +441,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
             const h2 szp = as_h2(cur.szw);
             const float sf = (float)szp[0], zf = (float)szp[1];
 #pragma unroll
-            for (int j = 0; j < (M < 4 ? M : 4); ++j) acc[j] += sf * ((P0[j] + P1[j]) - cur.ab[j].x) + zf * cur.ab[j].y;
+            for (int j = 0; j < NACC; ++j) acc[j] += sf * ((P0[j] + P1[j]) - cur.ab[j].x) + zf * cur.ab[j].y;
         }
         if (last_of_set) flush(rs_now);
     };
