@@ -203,6 +203,14 @@ __device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// gfx950 transposed LDS read: per 16-lane group a block of 4 rows x 16 columns of 16-bit elements comes back
+// column-major -- lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
+// EXEC must be all ones; results are visible after lds_wait().
+__device__ __forceinline__ u32x2 lds_read_tr8(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -460,19 +468,20 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
 
 // ---------------------------------------------------------------------------------------------------
 // Backward wrt input: dx[M,K] = dy[M,N] . Wdeq[N,K]  (contraction over n).
-// The contraction index is the packed layout's ROW index, so the weight tile is dequantised into LDS
-// transposed ([k][n], n contiguous) and both MFMA operands are read as 16-byte fragments in natural order.
-// Block tile: 128 (m) x 64 (k);  n advances 64 per stage.
+// The contraction index is the packed layout's ROW index: the B fragment of a lane is 8 consecutive n at ONE k, i.e.
+// a column of the weight tile.  The tile is dequantised into LDS row-major ([n][k]: two 16-byte writes per thread) and
+// read back through gfx950's transposing LDS read (ds_read_b64_tr_b16), two reads per fragment.
+// Block tile: 128 (m) x 64 (k);  n advances 64 per stage; global loads of the next stage are in flight during the MFMAs.
 // ---------------------------------------------------------------------------------------------------
 constexpr int DX_BM = 128, DX_BK = 64, DX_BN = 64;
-constexpr int WT_STRIDE = DX_BN + 8;  // halves; 144-byte rows keep 16-byte alignment and spread banks
+constexpr int WT_PITCH = 144;          // bytes per n row of the weight tile (64 k x 2 B + 16): 16-byte aligned, banks spread
 
 __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
                                                          const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                          const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
                                                          int K, int G, int n_out) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_a[DX_BM * DX_BN * 2];        // dy tile [128][64], swizzled slots
-    __shared__ __attribute__((aligned(16))) f16 lds_w[DX_BK * WT_STRIDE];            // W^T tile [64 k][64 n (+8)]
+    __shared__ __attribute__((aligned(16))) uint8_t lds_w[DX_BN * WT_PITCH];         // W tile [64 n][64 k (+8)] fp16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -492,60 +501,79 @@ __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__
     // W staging role: thread -> (n_local = tid>>2, chunk = (tid>>1)&1, half = tid&1): 16 of the 32 k of a chunk
     const int wn_l = tid >> 2, wch = (tid >> 1) & 1, whalf = tid & 1;
 
-    for (int n0 = 0; n0 < N; n0 += DX_BN) {
-        // ---- stage dy tile (natural k order inside each 32-chunk: slot s = dwords 4s..4s+3)
-        {
-            u32x4 v[4];
-            const f16* p = dy + (size_t)(bm0 + arow) * N + n0 + ach * 32;
+    // Two-stage software pipeline in registers: the global loads of tile n0 + 64 are issued before the MFMAs of tile
+    // n0, so HBM/L2 latency overlaps the matrix work instead of sitting between two barriers.
+    const int k0 = kt * 64 + wch * 32;
+    const bool outl_tile = ow != nullptr && k0 >= kq;          // block-uniform per (kt, wch) pair of the thread
+    struct Stage {
+        u32x4 a[4];      // dy: 64 bytes of row arow
+        u32x4 w[2];      // packed nibbles (w[0]) or 16 fp16 outlier weights
+        uint32_t sz;     // scale | scaled zero << 16
+    };
+    auto gload = [&](int n0, Stage& st) {
+        const f16* p = dy + (size_t)(bm0 + arow) * N + n0 + ach * 32;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = arow_ok && (n0 + ach * 32 + j * 8) < N;
-                v[j] = ok ? ((const u32x4*)p)[j] : u32x4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *(u32x4*)(lds_a + a_slot_off(arow, ach * 4 + j)) = v[j];
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = arow_ok && (n0 + ach * 32 + j * 8) < N;
+            st.a[j] = ok ? ((const u32x4*)p)[j] : u32x4{0u, 0u, 0u, 0u};
         }
-        // ---- stage W^T tile
-        {
-            const int n = n0 + wn_l;
-            const int k0 = kt * 64 + wch * 32;
-            f16 vals[16];
-            if (n < N) {
-                if (ow != nullptr && k0 >= kq) {
-                    const f16* p = ow + (size_t)n * n_out + (k0 - kq) + whalf * 16;
+        const int n = min(n0 + wn_l, N - 1);
+        if (outl_tile) {
+            const u32x4* po = (const u32x4*)(ow + (size_t)n * n_out + (k0 - kq) + whalf * 16);
+            st.w[0] = po[0];
+            st.w[1] = po[1];
+            st.sz = 0;
+        } else {
+            st.w[0] = *(const u32x4*)(qw + (size_t)(n >> 2) * K * 2 + (size_t)kt * 128 + (n & 3) * 32 + wch * 16);
+            st.w[1] = st.w[0];
+            const int g = k0 / G;
+            st.sz = (uint32_t)((const uint16_t*)scales)[(size_t)g * N + n] | ((uint32_t)((const uint16_t*)zeros)[(size_t)g * N + n] << 16);
+        }
+    };
+    auto lstore = [&](int n0, const Stage& st) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) vals[e] = p[e];
-                } else {
-                    const u32x4 q = *(const u32x4*)(qw + (size_t)(n >> 2) * K * 2 + (size_t)kt * 128 + (n & 3) * 32 + wch * 16);
-                    const int g = k0 / G;
-                    const h2 s = splat(scales[(size_t)g * N + n]), z = splat(zeros[(size_t)g * N + n]);
-                    // this thread owns k_local = whalf*16 .. +15 of the chunk: dwords d = whalf*8 .. +7; dword d = w + 4j
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        h2 wd[4];
-                        dequant8(q[w], s, z, wd);
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = whalf * 2 + jj;          // dword w+4j covers k = 2w+8j, +1
-                            const int e = (w + 4 * j - whalf * 8) * 2;
-                            vals[e] = wd[j][0];
-                            vals[e + 1] = wd[j][1];
-                        }
-                    }
-                }
+        for (int j = 0; j < 4; ++j) *(u32x4*)(lds_a + a_slot_off(arow, ach * 4 + j)) = st.a[j];
+        // this thread owns k_local = whalf*16 .. +15 of chunk wch of row wn_l: two runs of 8 consecutive k
+        u32x4 run[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        if (n0 + wn_l < N) {
+            if (outl_tile) {
+                run[0] = st.w[0];
+                run[1] = st.w[1];
             } else {
+                const h2 szp = as_h2(st.sz);
+                const h2 sc = splat(szp[0]), zc = splat(szp[1]);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) vals[e] = (f16)0.f;
+                for (int w = 0; w < 4; ++w) {
+                    h2 wd[4];
+                    dequant8(st.w[0][w], sc, zc, wd);            // wd[j] = pair (k = 8j + 2w, +1)
+                    run[0][w] = as_u32(whalf ? wd[2] : wd[0]);
+                    run[1][w] = as_u32(whalf ? wd[3] : wd[1]);
+                }
             }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) lds_w[(wch * 32 + whalf * 16 + e) * WT_STRIDE + wn_l] = vals[e];
         }
+        uint8_t* wrow = lds_w + wn_l * WT_PITCH + (wch * 32 + whalf * 16) * 2;
+        *(u32x4*)wrow = run[0];
+        *(u32x4*)(wrow + 16) = run[1];
+    };
+
+    // transposed-read address of this lane (step 0): group g = lane >> 4 -> columns wk*32 + (g & 1)*16 .., rows 8*(g >> 1) ..
+    const uint32_t wbase_tr = (uint32_t)(uintptr_t)lds_w +
+        (uint32_t)(8 * (lane >> 5) + ((lane & 15) >> 2)) * WT_PITCH + (uint32_t)(wk * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    Stage cur, nxt;
+    gload(0, cur);
+    for (int n0 = 0; n0 < N; n0 += DX_BN) {
+        lstore(n0, cur);
         __syncthreads();
+        if (n0 + DX_BN < N) gload(n0 + DX_BN, nxt);
         // ---- MFMA: 4 n-steps of 16
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // B fragment: lane (k col = wk*32 + r, h): n = s*16 + 8h .. +7
-            const h8 bf = *(const h8*)(&lds_w[(wk * 32 + r) * WT_STRIDE + s * 16 + h * 8]);
+            // B fragment: lane (k col = wk*32 + r, h): n = s*16 + 8h .. +7 -- a column of the [n][k] tile: two
+            // transposed reads (rows +0..3 and +4..7); lane 4q+p of its 16-lane group addresses row q, columns 4p..
+            const uint32_t tr0 = wbase_tr + (uint32_t)(s * 16) * WT_PITCH;
+            const u32x2 b_lo = lds_read_tr8(tr0), b_hi = lds_read_tr8(tr0 + 4 * WT_PITCH);
+            lds_wait();
+            const h8 bf = __builtin_bit_cast(h8, u32x4{b_lo[0], b_lo[1], b_hi[0], b_hi[1]});
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = wm * 64 + mt * 32 + r;
@@ -555,6 +583,7 @@ __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__
             }
         }
         __syncthreads();
+        cur = nxt;
     }
 
     const int kcol = kt * 64 + wk * 32 + r;
