@@ -565,15 +565,19 @@ __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__
         lstore(n0, cur);
         __syncthreads();
         if (n0 + DX_BN < N) gload(n0 + DX_BN, nxt);
-        // ---- MFMA: 4 n-steps of 16
+        // ---- MFMA: 4 n-steps of 16.  B fragment of lane (k col = wk*32 + r, h): n = s*16 + 8h .. +7 -- a column of
+        // the [n][k] tile: two transposed reads (rows +0..3 and +4..7); lane 4q+p of its 16-lane group addresses
+        // row q, columns 4p..  All 8 reads go out first, one wait.
+        u32x2 bt[8];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // B fragment: lane (k col = wk*32 + r, h): n = s*16 + 8h .. +7 -- a column of the [n][k] tile: two
-            // transposed reads (rows +0..3 and +4..7); lane 4q+p of its 16-lane group addresses row q, columns 4p..
-            const uint32_t tr0 = wbase_tr + (uint32_t)(s * 16) * WT_PITCH;
-            const u32x2 b_lo = lds_read_tr8(tr0), b_hi = lds_read_tr8(tr0 + 4 * WT_PITCH);
-            lds_wait();
-            const h8 bf = __builtin_bit_cast(h8, u32x4{b_lo[0], b_lo[1], b_hi[0], b_hi[1]});
+            bt[2 * s] = lds_read_tr8(wbase_tr + (uint32_t)(s * 16) * WT_PITCH);
+            bt[2 * s + 1] = lds_read_tr8(wbase_tr + (uint32_t)(s * 16 + 4) * WT_PITCH);
+        }
+        lds_wait();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 bf = __builtin_bit_cast(h8, u32x4{bt[2 * s][0], bt[2 * s][1], bt[2 * s + 1][0], bt[2 * s + 1][1]});
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int row = wm * 64 + mt * 32 + r;
@@ -596,8 +600,144 @@ __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__
         }
 }
 
+// Same algorithm with a 128 (m) x 128 (k) block tile (K % 128 == 0): every dy tile feeds twice the MFMAs, a thread
+// stages exactly one (row, 32-k chunk) = 16 packed bytes -> four 16-byte LDS writes.  4 waves as 2 (m) x 2 (k), each 64 x 64.
+constexpr int WT_PITCH2 = 272;         // bytes per n row of the [64 n][128 k] weight tile (256 + 16)
+
+__global__ __launch_bounds__(256) void gemm_w4_dx128_kernel(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
+                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
+                                                            const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
+                                                            int K, int G, int n_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_a[DX_BM * DX_BN * 2];        // dy tile [128][64], swizzled slots
+    __shared__ __attribute__((aligned(16))) uint8_t lds_w[DX_BN * WT_PITCH2];        // W tile [64 n][128 k (+8)] fp16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wk = wave & 1;  // wave tile: 64 (m) x 64 (k)
+    const int bm0 = blockIdx.x * DX_BM, kt = blockIdx.y;  // kt: 128-k tile index
+    const int kq = K - n_out;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int arow = tid >> 1, ach = tid & 1;
+    const bool arow_ok = bm0 + arow < M;
+    const int wn_l = tid >> 2, wch = tid & 3;             // W staging role: row n_local, 32-k chunk of the 128
+    const int k0 = kt * 128 + wch * 32;
+    const bool outl_chunk = ow != nullptr && k0 >= kq;
+
+    struct Stage {
+        u32x4 a[4];      // dy: 64 bytes of row arow
+        u32x4 w[4];      // packed nibbles (w[0]) or 32 fp16 outlier weights
+        uint32_t sz;     // scale | scaled zero << 16
+    };
+    auto gload = [&](int n0, Stage& st) {
+        const f16* p = dy + (size_t)(bm0 + arow) * N + n0 + ach * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = arow_ok && (n0 + ach * 32 + j * 8) < N;
+            st.a[j] = ok ? ((const u32x4*)p)[j] : u32x4{0u, 0u, 0u, 0u};
+        }
+        const int n = min(n0 + wn_l, N - 1);
+        if (outl_chunk) {
+            const u32x4* po = (const u32x4*)(ow + (size_t)n * n_out + (k0 - kq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st.w[j] = po[j];
+            st.sz = 0;
+        } else {
+            st.w[0] = *(const u32x4*)(qw + (size_t)(n >> 2) * K * 2 + (size_t)(k0 >> 6) * 128 + (n & 3) * 32 + ((k0 >> 5) & 1) * 16);
+            const int g = k0 / G;
+            st.sz = (uint32_t)((const uint16_t*)scales)[(size_t)g * N + n] | ((uint32_t)((const uint16_t*)zeros)[(size_t)g * N + n] << 16);
+        }
+    };
+    auto lstore = [&](int n0, const Stage& st) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4*)(lds_a + a_slot_off(arow, ach * 4 + j)) = st.a[j];
+        u32x4 run[4];    // run j = the 8 consecutive k 8j .. 8j+7 of the chunk
+        if (n0 + wn_l >= N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) run[j] = u32x4{0u, 0u, 0u, 0u};
+        } else if (outl_chunk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) run[j] = st.w[j];
+        } else {
+            const h2 szp = as_h2(st.sz);
+            const h2 sc = splat(szp[0]), zc = splat(szp[1]);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                h2 wd[4];
+                dequant8(st.w[0][w], sc, zc, wd);            // wd[j] = pair (k = 8j + 2w, +1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) run[j][w] = as_u32(wd[j]);
+            }
+        }
+        uint8_t* wrow = lds_w + wn_l * WT_PITCH2 + wch * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4*)(wrow + 16 * j) = run[j];
+    };
+
+    // transposed-read address of this lane for k-half 0, n-step 0 (see gemm_w4_dx_kernel)
+    const uint32_t wbase_tr = (uint32_t)(uintptr_t)lds_w +
+        (uint32_t)(8 * (lane >> 5) + ((lane & 15) >> 2)) * WT_PITCH2 + (uint32_t)(wk * 64 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    Stage cur, nxt;
+    gload(0, cur);
+    for (int n0 = 0; n0 < N; n0 += DX_BN) {
+        lstore(n0, cur);
+        __syncthreads();
+        if (n0 + DX_BN < N) gload(n0 + DX_BN, nxt);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x2 bt[4];
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bt[2 * kh] = lds_read_tr8(wbase_tr + (uint32_t)(s * 16) * WT_PITCH2 + kh * 64);
+                bt[2 * kh + 1] = lds_read_tr8(wbase_tr + (uint32_t)(s * 16 + 4) * WT_PITCH2 + kh * 64);
+            }
+            h8 af[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                af[mt] = *(const h8*)(lds_a + a_slot_off(wm * 64 + mt * 32 + r, (s >> 1) * 4 + (s & 1) * 2 + h));
+            lds_wait();
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const h8 bf = __builtin_bit_cast(h8, u32x4{bt[2 * kh][0], bt[2 * kh][1], bt[2 * kh + 1][0], bt[2 * kh + 1][1]});
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt][kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf, acc[mt][kh], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int kcol = kt * 128 + wk * 64 + kh * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M) dx[(size_t)m * K + kcol] = (f16)acc[mt][kh][e];
+            }
+        }
+}
+
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st) {
+    // the 128-wide tile when it still gives every CU a block; smaller problems keep the 64-wide tile (twice the blocks)
+    if (K % 128 == 0 && n_out % 32 == 0 && ((M + DX_BM - 1) / DX_BM) * (K / 128) >= 256) {
+        dim3 grid2((M + DX_BM - 1) / DX_BM, K / 128);
+        hipLaunchKernelGGL(gemm_w4_dx128_kernel, grid2, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
+                           (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
+                           (f16*)dx, M, N, K, G, n_out);
+        return hipGetLastError();
+    }
     dim3 grid((M + DX_BM - 1) / DX_BM, K / DX_BK);
     hipLaunchKernelGGL(gemm_w4_dx_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
                        (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
