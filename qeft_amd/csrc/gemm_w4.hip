@@ -788,8 +788,113 @@ __global__ __launch_bounds__(256) void grad_oweight_kernel(const f16* __restrict
         }
 }
 
+// MFMA version.  d_oweight = dy^T . x_o contracts over m, the ROW index of both operands, so both MFMA fragments are
+// columns of row-major tiles: [128 m][32 n] of dy and [128 m][64 j] of x_o are staged as they lie in HBM (16-byte
+// copies) and read back with the transposing LDS read (as the weight tile of gemm_w4_dx_kernel).  Block = 32 (n) x 64
+// (j) outputs over ALL m (no cross-block reduction: deterministic); its 4 waves take alternate 16-m steps and are
+// summed through LDS in wave order at the end.  The first version (fp32 FMAs on an LDS tile) took longer than the dX
+// GEMM although it has 3 % of its flops.
+constexpr int GO_BN = 32, GO_BJ = 64, GO_BM = 128;
+constexpr int GO_PDY = GO_BN * 2 + 16;   // bytes per m row of the dy tile
+constexpr int GO_PX = GO_BJ * 2 + 16;    // bytes per m row of the x_o tile
+
+__global__ __launch_bounds__(256) void grad_oweight_mfma_kernel(const f16* __restrict__ dy, const f16* __restrict__ x,
+                                                                float* __restrict__ dow, int M, int N, int K, int R) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds_dy[GO_BM * GO_PDY];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_x[GO_BM * GO_PX];
+    __shared__ float red[4][2][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * GO_BN, j0 = blockIdx.y * GO_BJ, kq = K - R;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    struct Stage {
+        u32x4 d[2];    // dy: items tid, tid + 256 -> (row = item >> 2, 16-byte piece = item & 3)
+        u32x4 xv[4];   // x_o: items tid + 256 i  -> (row = item >> 3, piece = item & 7)
+    };
+    auto gload = [&](int m0, Stage& st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + 256 * i, m = m0 + (item >> 2), n = n0 + (item & 3) * 8;
+            st.d[i] = (m < M && n < N) ? *(const u32x4*)(dy + (size_t)m * N + n) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = tid + 256 * i, m = m0 + (item >> 3), j = j0 + (item & 7) * 8;
+            st.xv[i] = (m < M && j < R) ? *(const u32x4*)(x + (size_t)m * K + kq + j) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto lstore = [&](const Stage& st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + 256 * i;
+            *(u32x4*)(lds_dy + (item >> 2) * GO_PDY + (item & 3) * 16) = st.d[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = tid + 256 * i;
+            *(u32x4*)(lds_x + (item >> 3) * GO_PX + (item & 7) * 16) = st.xv[i];
+        }
+    };
+    // transposed-read addresses (16-m step 0): lane 4q+p of a 16-lane group addresses row q, columns 4p.. of its block;
+    // group g = lane >> 4 -> columns (g & 1)*16 .., contraction rows 8*(g >> 1) ..
+    const uint32_t rowsel = (uint32_t)(8 * (lane >> 5) + ((lane & 15) >> 2));
+    const uint32_t colsel = (uint32_t)(((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    const uint32_t a_tr = (uint32_t)(uintptr_t)lds_dy + rowsel * GO_PDY + colsel;
+    const uint32_t b_tr = (uint32_t)(uintptr_t)lds_x + rowsel * GO_PX + colsel;
+
+    Stage cur, nxt;
+    gload(0, cur);
+    for (int m0 = 0; m0 < M; m0 += GO_BM) {
+        lstore(cur);
+        __syncthreads();
+        if (m0 + GO_BM < M) gload(m0 + GO_BM, nxt);
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const uint32_t row = (uint32_t)(wave * 2 + ss) * 16;
+            const u32x2 a0 = lds_read_tr8(a_tr + row * GO_PDY), a1 = lds_read_tr8(a_tr + (row + 4) * GO_PDY);
+            u32x2 b[2][2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                b[jt][0] = lds_read_tr8(b_tr + row * GO_PX + jt * 64);
+                b[jt][1] = lds_read_tr8(b_tr + (row + 4) * GO_PX + jt * 64);
+            }
+            lds_wait();
+            const h8 af = __builtin_bit_cast(h8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    af, __builtin_bit_cast(h8, u32x4{b[jt][0][0], b[jt][0][1], b[jt][1][0], b[jt][1][1]}), acc[jt], 0, 0, 0);
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave][jt][e][lane] = acc[jt][e];
+    __syncthreads();
+    for (int idx = tid; idx < 2 * 16 * 64; idx += 256) {
+        const int jt = idx >> 10, e = (idx >> 6) & 15, l = idx & 63;
+        const float v = ((red[0][jt][e][l] + red[1][jt][e][l]) + red[2][jt][e][l]) + red[3][jt][e][l];
+        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), j = j0 + jt * 32 + (l & 31);
+        if (n < N && j < R) dow[(size_t)n * R + j] = v;
+    }
+}
+
 hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, int N, int K, int n_out,
                                hipStream_t st) {
+    if (N % 8 == 0 && n_out % 8 == 0 && K % 8 == 0) {   // 16-byte row pieces
+        dim3 grid2((N + GO_BN - 1) / GO_BN, (n_out + GO_BJ - 1) / GO_BJ);
+        hipLaunchKernelGGL(grad_oweight_mfma_kernel, grid2, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (float*)dow, M,
+                           N, K, n_out);
+        return hipGetLastError();
+    }
     dim3 grid((N + 63) / 64, (n_out + 63) / 64);
     hipLaunchKernelGGL(grad_oweight_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (float*)dow, M, N, K,
                        n_out);
