@@ -18,6 +18,10 @@ The same JSON line carries
                 their HIP-event-timed duration (the token's GEMV launches replayed back to back from a graph on the
                 launch stream; the event time includes the ~1.3 us inter-kernel gaps, as rocprofv3's kernel-trace
                 durations on this stack do -- the two agree), against 8 TB/s.
+                roofline.traffic = HBM bytes per GEMV launch from the PMC counters: a short child run of this script
+                under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (started before this process touches the GPU),
+                FETCH_SIZE x 1024 x 2 (gfx950 correction); null if rocprofv3 is not available.
+                roofline.per_launch_kind = the same timing, one GEMV of the layer at a time.
   cpu_baseline  the reference's CPU path (dense nn.Linear on the dequantised weights, oracle/) timed on the host cores
                 for the 7 linears of one layer, scaled to a token.
 """
@@ -68,6 +72,40 @@ def cpu_baseline(shape, reps=8):
                       f"median of {reps}; linears only, x{shape.n_layers} layers"}
 
 
+def hbm_traffic_per_gemv_launch(model_flag, bits):
+    """HBM bytes per GEMV launch from the PMC counters, collected exactly as MI355X_MICROARCH.md prescribes: a run of
+    its own under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (nothing else traced), a short CHILD run of this script
+    started before this process touches the GPU; FETCH_SIZE is in KiB and, on gfx950, reports half of the bytes of a
+    wide streaming read -> x 1024 x 2.  Returns None if the profiler is not there or anything goes wrong."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="qeft_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "run", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "4", "--model", model_flag,
+               "--bits", str(bits), "--no-cpu-baseline", "--no-traffic", "--no-per-kind"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        vals = []
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == "FETCH_SIZE" and "gemv_w4_mfma" in r.get("Kernel_Name", ""):
+                    vals.append(float(r["Counter_Value"]))
+        if not vals:
+            return None
+        return {"bytes_per_launch": int(sum(vals) / len(vals) * 1024 * 2), "launches_sampled": len(vals)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +117,8 @@ def main():
                          "3: this build's 3-bit extension layout (config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the PMC child run that fills roofline.traffic")
+    ap.add_argument("--no-per-kind", action="store_true", help="skip the per-launch-kind timing graphs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,6 +127,10 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # the PMC pass is a child process of its own and has to start BEFORE this process initialises the GPU
+    traffic = None
+    if world == 1 and "RANK" not in os.environ and not args.no_traffic:
+        traffic = hbm_traffic_per_gemv_launch(args.model, args.bits)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -166,7 +210,11 @@ def main():
                 "kernel": "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel (4 launches per layer)",
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3)}
         # the same, one GEMV of the layer at a time (32 launches per replay): per-kernel rates for DESIGN.md / rocprof
-        if g2 is not None and world == 1:
+        if traffic is not None:
+            roof["traffic"] = traffic["bytes_per_launch"]
+            roof["traffic_note"] = (f"FETCH_SIZE x 1024 x 2 (gfx950 correction), mean over {traffic['launches_sampled']} "
+                                    "GEMV launches of a separate `rocprofv3 --pmc FETCH_SIZE --kernel-trace` child run")
+        if g2 is not None and world == 1 and not args.no_per_kind:
             per = {}
             lin0 = eng.lin[0]
             parts = {"qkv": ("q", "k", "v"), "o": ("o",), "gu": ("g", "u"), "d": ("d",)}
