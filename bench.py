@@ -85,6 +85,9 @@ def hbm_traffic_per_gemv_launch(model_flag, bits):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    # already running under a profiler (e.g. `rocprofv3 --stats -- python3 bench.py`): do not nest another one
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     tmp = tempfile.mkdtemp(prefix="qeft_pmc_", dir="/tmp")
     try:
         cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "run", "--output-format", "csv", "--",
