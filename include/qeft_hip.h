@@ -97,6 +97,12 @@ int qeft_gemm_w4_ws(const void* x, const void* qweight, const void* scales, cons
 int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
                     const void* oweight, void* dx, int m, int n, int k, int group_size, int n_out,
                     qeft_stream_t stream);
+/* The same with a scratch buffer (as qeft_gemm_w4_ws): few output tiles and a long contraction over n -> the n loop is
+ * cut into parts, fp32 partials in `workspace`, summed in a fixed order. */
+long long qeft_gemm_w4_dx_workspace_bytes(int m, int n, int k);
+int qeft_gemm_w4_dx_ws(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
+                       const void* oweight, void* dx, void* workspace, long long workspace_bytes, int m, int n, int k,
+                       int group_size, int n_out, qeft_stream_t stream);
 
 /* Gradient of the trainable outlier slice: d_oweight[N, r] (fp32) = dy[M,N]^T . x[M, K-r:]  (qlinear.py:41-42). */
 int qeft_grad_oweight(const void* dy, const void* x, void* d_oweight_f32, int m, int n, int k, int n_out,

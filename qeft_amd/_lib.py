@@ -30,6 +30,8 @@ SIGNATURES = {
     "qeft_gemm_w4_workspace_bytes": [_i, _i, _i, _i],
     "qeft_gemm_w4_ws": [_p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_dx": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemm_w4_dx_workspace_bytes": [_i, _i, _i],
+    "qeft_gemm_w4_dx_ws": [_p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p],
     "qeft_grad_oweight": [_p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_dequant_w4": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_pack_oweight": [_p, _p, _i, _i, _p],
@@ -67,7 +69,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == "qeft_error_string" else
-                          ctypes.c_longlong if name == "qeft_gemm_w4_workspace_bytes" else _i)
+                          ctypes.c_longlong if name in ("qeft_gemm_w4_workspace_bytes", "qeft_gemm_w4_dx_workspace_bytes") else _i)
         _lib = l
     return _lib
 

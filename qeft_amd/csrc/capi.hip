@@ -34,7 +34,9 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                           void* workspace = nullptr, size_t workspace_bytes = 0);
 int gemm_w4_split(int M, int N, int K, int n_out);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
-                             void* dx, int M, int N, int K, int G, int n_out, hipStream_t st);
+                             void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace = nullptr,
+                             size_t workspace_bytes = 0);
+int gemm_w4_dx_split(int M, int N, int K);
 hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, int N, int K, int n_out,
                                hipStream_t st);
 }  // namespace qeft
@@ -202,9 +204,9 @@ int qeft_gemm_w4_ws(const void* x, const void* qweight, const void* scales, cons
                      workspace && workspace_bytes > 0 ? (size_t)workspace_bytes : 0);
 }
 
-int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
-                    const void* oweight, void* dx, int m, int n, int k, int group_size, int n_out,
-                    qeft_stream_t stream) {
+static int gemm_dx_impl(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
+                        const void* oweight, void* dx, int m, int n, int k, int group_size, int n_out,
+                        qeft_stream_t stream, void* workspace, size_t workspace_bytes) {
     if (m < 1) return QEFT_ERR_SHAPE;
     if (!oweight) n_out = 0;
     if (int e = check_common(n, k, group_size, n_out)) return e;
@@ -213,7 +215,28 @@ int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, con
     if (!aligned16(dy) || !aligned16(qweight) || !aligned16(dx) || (n_out > 0 && !aligned16(oweight)))
         return QEFT_ERR_ALIGN;
     return finish(qeft::gemm_w4_dx_launch(dy, qweight, scales, scaled_zeros, oweight, dx, m, n, k, group_size, n_out,
-                                          (hipStream_t)stream));
+                                          (hipStream_t)stream, workspace, workspace_bytes));
+}
+
+int qeft_gemm_w4_dx(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
+                    const void* oweight, void* dx, int m, int n, int k, int group_size, int n_out,
+                    qeft_stream_t stream) {
+    return gemm_dx_impl(dy, qweight, scales, scaled_zeros, oweight, dx, m, n, k, group_size, n_out, stream, nullptr, 0);
+}
+
+long long qeft_gemm_w4_dx_workspace_bytes(int m, int n, int k) {
+    if (m < 1 || n < 1 || k < 64 || k % 4 != 0) return 0;
+    if (k % 128 == 0 && ((m + 127) / 128) * (k / 128) >= 512) return 0;       // the 128-wide tile: no split
+    const int s = qeft::gemm_w4_dx_split(m, n, k);
+    return s > 1 ? (long long)s * m * k * 4 : 0;
+}
+
+int qeft_gemm_w4_dx_ws(const void* dy, const void* qweight, const void* scales, const void* scaled_zeros,
+                       const void* oweight, void* dx, void* workspace, long long workspace_bytes, int m, int n, int k,
+                       int group_size, int n_out, qeft_stream_t stream) {
+    if (workspace && !aligned16(workspace)) return QEFT_ERR_ALIGN;
+    return gemm_dx_impl(dy, qweight, scales, scaled_zeros, oweight, dx, m, n, k, group_size, n_out, stream, workspace,
+                        workspace && workspace_bytes > 0 ? (size_t)workspace_bytes : 0);
 }
 
 int qeft_grad_oweight(const void* dy, const void* x, void* d_oweight_f32, int m, int n, int k, int n_out,

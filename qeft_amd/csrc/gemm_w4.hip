@@ -479,7 +479,9 @@ constexpr int WT_PITCH = 144;          // bytes per n row of the weight tile (64
 __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
                                                          const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                          const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
-                                                         int K, int G, int n_out) {
+                                                         int K, int G, int n_out, float* __restrict__ part) {
+    // gridDim.z = S > 1 (few output tiles, long contraction): block z contracts the n-tiles [nt*z/S, nt*(z+1)/S) and
+    // writes an fp32 partial tile to part[z][M][K]; gemm_splitk_reduce_kernel sums them in order.
     __shared__ __attribute__((aligned(16))) uint8_t lds_a[DX_BM * DX_BN * 2];        // dy tile [128][64], swizzled slots
     __shared__ __attribute__((aligned(16))) uint8_t lds_w[DX_BN * WT_PITCH];         // W tile [64 n][64 k (+8)] fp16
 
@@ -559,12 +561,14 @@ __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__
     // transposed-read address of this lane (step 0): group g = lane >> 4 -> columns wk*32 + (g & 1)*16 .., rows 8*(g >> 1) ..
     const uint32_t wbase_tr = (uint32_t)(uintptr_t)lds_w +
         (uint32_t)(8 * (lane >> 5) + ((lane & 15) >> 2)) * WT_PITCH + (uint32_t)(wk * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+    const int ntiles = (N + DX_BN - 1) / DX_BN, S = gridDim.z, z = blockIdx.z;
+    const int n_lo = (int)((long long)ntiles * z / S) * DX_BN, n_hi = min((int)((long long)ntiles * (z + 1) / S) * DX_BN, N);
     Stage cur, nxt;
-    gload(0, cur);
-    for (int n0 = 0; n0 < N; n0 += DX_BN) {
+    gload(n_lo, cur);
+    for (int n0 = n_lo; n0 < n_hi; n0 += DX_BN) {
         lstore(n0, cur);
         __syncthreads();
-        if (n0 + DX_BN < N) gload(n0 + DX_BN, nxt);
+        if (n0 + DX_BN < n_hi) gload(n0 + DX_BN, nxt);
         // ---- MFMA: 4 n-steps of 16.  B fragment of lane (k col = wk*32 + r, h): n = s*16 + 8h .. +7 -- a column of
         // the [n][k] tile: two transposed reads (rows +0..3 and +4..7); lane 4q+p of its 16-lane group addresses
         // row q, columns 4p..  All 8 reads go out first, one wait.
@@ -596,7 +600,10 @@ __global__ __launch_bounds__(256) void gemm_w4_dx_kernel(const f16* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int m = bm0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m < M) dx[(size_t)m * K + kcol] = (f16)acc[mt][e];
+            if (m < M) {
+                if (S > 1) part[((size_t)z * M + m) * K + kcol] = acc[mt][e];
+                else dx[(size_t)m * K + kcol] = (f16)acc[mt][e];
+            }
         }
 }
 
@@ -728,20 +735,40 @@ __global__ __launch_bounds__(256) void gemm_w4_dx128_kernel(const f16* __restric
         }
 }
 
+// Split factor of the contraction (n) for dX: only when the 128 x 64 tiling gives too few blocks to hide the latency of
+// a long n loop.
+int gemm_w4_dx_split(int M, int N, int K) {
+    const int blocks = ((M + DX_BM - 1) / DX_BM) * (K / DX_BK), ntiles = (N + DX_BN - 1) / DX_BN;
+    if (blocks >= 1024 || ntiles < 32) return 1;
+    int s = 1024 / blocks;             // measured: ~4 resident blocks per CU in total
+    if (s > ntiles / 16) s = ntiles / 16;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
+
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
-                             void* dx, int M, int N, int K, int G, int n_out, hipStream_t st) {
-    // the 128-wide tile when it still gives every CU a block; smaller problems keep the 64-wide tile (twice the blocks)
-    if (K % 128 == 0 && n_out % 32 == 0 && ((M + DX_BM - 1) / DX_BM) * (K / 128) >= 256) {
+                             void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace,
+                             size_t workspace_bytes) {
+    // the 128-wide tile when it still gives every CU two blocks; smaller problems keep the 64-wide tile (twice the
+    // blocks, and a split over n below 512 of them)
+    if (K % 128 == 0 && n_out % 32 == 0 && ((M + DX_BM - 1) / DX_BM) * (K / 128) >= 512) {
         dim3 grid2((M + DX_BM - 1) / DX_BM, K / 128);
         hipLaunchKernelGGL(gemm_w4_dx128_kernel, grid2, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
                            (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
                            (f16*)dx, M, N, K, G, n_out);
         return hipGetLastError();
     }
-    dim3 grid((M + DX_BM - 1) / DX_BM, K / DX_BK);
+    int S = workspace ? gemm_w4_dx_split(M, N, K) : 1;
+    while (S > 1 && (size_t)S * M * K * 4 > workspace_bytes) --S;
+    dim3 grid((M + DX_BM - 1) / DX_BM, K / DX_BK, S);
     hipLaunchKernelGGL(gemm_w4_dx_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
                        (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
-                       (f16*)dx, M, N, K, G, n_out);
+                       (f16*)dx, M, N, K, G, n_out, (float*)workspace);
+    if (S > 1) {
+        const size_t quads = (size_t)M * K / 4;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, st,
+                           (const float*)workspace, (const f16*)nullptr, (f16*)dx, M, K, S);
+    }
     return hipGetLastError();
 }
 

@@ -164,9 +164,19 @@ def gemm_4bit_dx(grad_out, kernel, scales, zeros, oweights):
     n_out = oweights.shape[1] if oweights is not None else 0
     out = torch.empty(*grad_out.shape[:-1], k, dtype=grad_out.dtype, device=grad_out.device)
     with torch.cuda.device(dy.device):
-        _lib.check(_lib.lib().qeft_gemm_w4_dx(dy.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-                                              oweights.data_ptr() if n_out else None, out.data_ptr(), m, n, k, group,
-                                              n_out, _stream(dy)))
+        lib = _lib.lib()
+        st = _stream(dy)
+        need = lib.qeft_gemm_w4_dx_workspace_bytes(m, n, k)
+        ws = None
+        if need > 0:      # few output tiles, long contraction: split over n through the per-(device, stream) scratch
+            key = (dy.device.index, st)
+            ws = _GEMM_WS.get(key)
+            if ws is None or ws.numel() * 4 < need:
+                ws = _GEMM_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.qeft_gemm_w4_dx_ws(dy.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                          oweights.data_ptr() if n_out else None, out.data_ptr(),
+                                          ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0,
+                                          m, n, k, group, n_out, st))
     return out
 
 

@@ -138,3 +138,24 @@ def test_gemm_split_k_path_vs_oracle(m, n, k, r):
                                        torch.cuda.current_stream(DEV).cuda_stream))
         torch.cuda.synchronize()
         assert rel_err(out.cpu().numpy(), yref) < REL_TOL
+
+
+@pytest.mark.parametrize("m,n,k,r", [(300, 4096, 512, 128), (130, 2560, 256, 0)])
+def test_dx_split_over_n_vs_oracle(m, n, k, r):
+    """Backward wrt the input with few output tiles and a long contraction: the n loop is cut into parts (fp32 partials
+    in a workspace, fixed summation order)."""
+    from qeft_amd import _lib, qeft_cuda
+    g = 128
+    assert _lib.lib().qeft_gemm_w4_dx_workspace_bytes(m, n, k) >= 2 * m * k * 4
+    assert _lib.lib().qeft_gemm_w4_dx_workspace_bytes(4096, 4096, 4096) == 0
+    bufs = O.make_layer(n, k, r, g, seed=m + 1)
+    t = layer_to_torch(bufs, DEV)
+    dy = (torch.randn(m, n, generator=torch.Generator().manual_seed(2)) * 0.1).half()
+    x = O.make_activation(m, k, r, seed=4)
+    dx = qeft_cuda.gemm_4bit_dx(dy.to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight"))
+    dx2 = qeft_cuda.gemm_4bit_dx(dy.to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight"))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx2)
+    dx_ref, _ = O.quant_linear_backward(dy.numpy(), x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"],
+                                        bufs.get("oweight"), g)
+    assert rel_err(dx.cpu().numpy(), dx_ref) < 2e-3
