@@ -193,6 +193,60 @@ class QuantLlama(nn.Module):
         return rms(h, self.model.norm) @ self.lm_head.weight.float().T
 
 
+def _rmsnorm(x, gamma, eps):
+    """[T, H] fp16 -> fp16 through the C ABI (qeft_rmsnorm), current stream."""
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().qeft_rmsnorm(x.data_ptr(), None, gamma.data_ptr(), None, y.data_ptr(), x.shape[0], x.shape[1],
+                                       eps, torch.cuda.current_stream(x.device).cuda_stream))
+    return y
+
+
+def _silu_mul(gate, up):
+    out = torch.empty_like(gate)
+    _lib.check(_lib.lib().qeft_silu_mul(gate.data_ptr(), up.data_ptr(), out.data_ptr(), gate.numel(),
+                                        torch.cuda.current_stream(gate.device).cuda_stream))
+    return out
+
+
+@torch.no_grad()
+def prefill(model: "QuantLlama", tokens, engine=None):
+    """Batched forward over T prompt tokens through the packed QuantLinears: T >= 8 rows take the MFMA GEMM path
+    (fused outlier slice; BASELINE config 3), attention is torch's causal SDPA in fp16.  Returns fp16 logits
+    [T, vocab].  With `engine` (a DecodeEngine of the same model) the rotated keys and the values are written into its
+    KV caches and its position is set to T, so decoding continues from the prompt (main.py:340-371 feeds the prompt
+    token by token; this is the batched equivalent)."""
+    s = model.shape
+    T = tokens.numel()
+    assert T <= s.max_seq
+    h = model.model.embed_tokens.weight[tokens]                       # [T, hidden] fp16
+    cos, sin = model.rope_cos[:T, None, :], model.rope_sin[:T, None, :]
+
+    def rope(x):                                                      # [T, H, 128] fp16 -> rotated fp16 (fp32 math)
+        a, b = x[..., :64].float(), x[..., 64:].float()
+        return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1).half()
+
+    for li, L in enumerate(model.model.layers):
+        at, mlp = L.self_attn, L.mlp
+        x = _rmsnorm(h, L.input_layernorm, s.rms_eps)
+        q = rope(at.q_proj(x).view(T, s.n_heads, 128))
+        k = rope(at.k_proj(x).view(T, s.n_kv_heads, 128))
+        v = at.v_proj(x).view(T, s.n_kv_heads, 128)
+        if engine is not None:
+            engine.kc[li][:, :T] = k.transpose(0, 1)
+            engine.vc[li][:, :T] = v.transpose(0, 1)
+        rep = s.n_heads // s.n_kv_heads
+        kk, vv = (k, v) if rep == 1 else (k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1))
+        a = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1), kk.transpose(0, 1), vv.transpose(0, 1),
+                                                             is_causal=True)           # [H, T, 128]
+        a = a.transpose(0, 1).reshape(T, s.hidden).contiguous()
+        h = h + at.o_proj(a)                                          # o_proj gathers its own column order
+        x = _rmsnorm(h, L.post_attention_layernorm, s.rms_eps)
+        h = h + mlp.down_proj(_silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
+    if engine is not None:
+        engine.pos.fill_(T)
+    return torch.matmul(_rmsnorm(h, model.model.norm, s.rms_eps), model.lm_head.weight.t())
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):

@@ -302,3 +302,31 @@ def test_token_begin_end_match_torch(vocab, hidden):
     _lib.check(lib.qeft_token_end(None, None, pos.data_ptr(), vocab, 0, _st()))    # not greedy: only the position moves
     torch.cuda.synchronize()
     assert int(tok.item()) == before and int(pos.item()) == 22
+
+
+def test_prefill_matches_dense_model_and_hands_over_to_decode():
+    """Batched prompt pass through the packed linears (GEMM path) == the dense fp32 model within tolerance, and decoding
+    from its KV caches == decoding the whole sequence token by token."""
+    from qeft_amd.llama import DecodeEngine, QuantLlama, nll_from_logits, prefill, tiny_shape
+    shape = tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=384, max_seq=64)
+    model = QuantLlama(shape, DEV, seed=6)
+    tokens = torch.randint(0, shape.vocab, (37,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    T = 32
+    eng = DecodeEngine(model, use_graph=False)
+    got = prefill(model, tokens[:T], eng).float()
+    ref = model.forward_dense_reference(tokens[:T])
+    torch.cuda.synchronize()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-2
+    assert abs(nll_from_logits(got, tokens[:T]) - nll_from_logits(ref, tokens[:T])) < 5e-3
+    assert int(eng.pos.item()) == T
+    # continue decoding 5 tokens from the prefilled caches; compare with a token-by-token run of everything
+    outs = []
+    for t in tokens[T:].tolist():
+        eng.tok.fill_(t)
+        eng.step()
+        outs.append(eng.logits[0].float().clone())
+    cont = torch.stack(outs)
+    full = DecodeEngine(model, use_graph=False).teacher_forced_logits(tokens)[T:]
+    torch.cuda.synchronize()
+    assert (cont - full).abs().max().item() / full.abs().max().item() < 2e-2
+    assert (cont.argmax(-1) == full.argmax(-1)).float().mean().item() >= 0.8
