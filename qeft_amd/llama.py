@@ -272,8 +272,14 @@ class DecodeEngine:
         self.lib = _lib.lib()
         self.tp_group = tp_group
         self.bits = getattr(s, "bits", 4)
-        self.P = dist.get_world_size(tp_group) if tp_group is not None else 1
-        self.rank = dist.get_rank(tp_group) if tp_group is not None else 0
+        # tp_group: a torch.distributed group (RCCL), or any object with .world, .rank and .all_gather(out, inp) -- the
+        # tests drive two ranks of one process in lock step through such an object (tests/test_gpu_tp.py)
+        self.sim_group = tp_group if hasattr(tp_group, "all_gather") else None
+        if self.sim_group is not None:
+            self.P, self.rank = tp_group.world, tp_group.rank
+        else:
+            self.P = dist.get_world_size(tp_group) if tp_group is not None else 1
+            self.rank = dist.get_rank(tp_group) if tp_group is not None else 0
         self.tp = tp_group is not None      # a 1-rank group still runs the sharded launch sequence + collectives
         P, tp = self.P, self.tp
         f16 = dict(dtype=torch.float16, device=dev)
@@ -350,6 +356,13 @@ class DecodeEngine:
     def h(self):
         return self.hbuf[0]
 
+    def _all_gather(self, out, inp):
+        if self.sim_group is not None:
+            self.sim_group.all_gather(out, inp)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out, inp, group=self.tp_group)
+
     def reset(self):
         self.pos.zero_()
 
@@ -402,7 +415,7 @@ class DecodeEngine:
             ck(group_qkv(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
                          s.hidden, g, no, st))
             if tp:
-                dist.all_gather_into_tensor(self.qkv_all.view(-1), self.qkv_loc, group=self.tp_group)
+                self._all_gather(self.qkv_all.view(-1), self.qkv_loc)
                 self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
                 self.k.view(P, self.kvs).copy_(self.qkv_all[:, self.hs:self.hs + self.kvs])
                 self.v.view(P, self.kvs).copy_(self.qkv_all[:, self.hs + self.kvs:])
@@ -420,7 +433,7 @@ class DecodeEngine:
             if tp:
                 ck(fused_o(self.att.data_ptr(), o, ow_o, h[r0:r0 + self.hs].data_ptr(), szp_o, self.h_loc.data_ptr(),
                            self.hs, s.hidden))
-                dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
+                self._all_gather(h2, self.h_loc)
                 h, h2 = h2, h
             else:
                 ck(fused_o(self.att.data_ptr(), o, ow_o, h.data_ptr(), szp_o, h.data_ptr(), s.hidden, s.hidden))
@@ -431,7 +444,7 @@ class DecodeEngine:
                 if not linears_only:
                     ck(lib.qeft_silu_mul(self.gate_loc.data_ptr(), self.up_loc.data_ptr(), self.act_loc.data_ptr(),
                                          self.its, st))
-                dist.all_gather_into_tensor(self.act, self.act_loc, group=self.tp_group)
+                self._all_gather(self.act, self.act_loc)
             d = lin["d"]
             ow_d = d.oweight_interleaved.data_ptr() if no else None
             szp_d = d._szp(d.scales)
@@ -439,7 +452,7 @@ class DecodeEngine:
             if tp:
                 ck(fused_d(self.act.data_ptr(), d, ow_d, h[r0:r0 + self.hs].data_ptr(), szp_d, self.h_loc.data_ptr(),
                            self.hs, s.inter))
-                dist.all_gather_into_tensor(h2, self.h_loc, group=self.tp_group)
+                self._all_gather(h2, self.h_loc)
                 h, h2 = h2, h
             else:
                 # silu(gate) * up is formed while down_proj stages its input

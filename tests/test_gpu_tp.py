@@ -50,3 +50,65 @@ def test_sharded_quantlinear_on_rccl(world_of_one):
     for m in (1, 5, 40):
         x = torch.randn(m, 512, device=DEV).half()
         assert torch.equal(sh(x), ql(x))
+
+
+class _LockstepGroup:
+    """Two (or more) ranks of ONE process, one thread each, sharing the GPU's default stream: all_gather = everybody
+    publishes its slice, meets at a barrier, copies all slices (stream order makes them ready), meets again (nobody
+    overwrites a slice somebody still has to copy).  Stands in for the process group so that the P > 1 launch sequence
+    of the decode engine -- shard offsets, slice reassembly, residual slices -- runs on a one-GPU box."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world)
+
+    def view(self, rank):
+        parent = self
+
+        class _Rank:
+            world, slots, barrier = parent.world, parent.slots, parent.barrier
+
+            def __init__(self):
+                self.rank = rank
+
+            def all_gather(self, out, inp):
+                self.slots[self.rank] = inp
+                self.barrier.wait()
+                out.view(self.world, -1).copy_(torch.stack([t.reshape(-1) for t in self.slots]))
+                self.barrier.wait()
+        return _Rank()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_engine_two_ranks_in_lockstep_equal_single_gpu_engine(world):
+    import threading
+    from qeft_amd.llama import DecodeEngine, QuantLlama, tiny_shape
+    shape = tiny_shape(n_layers=2, hidden=512, inter=1024, n_heads=4, vocab=512, max_seq=64)
+    model = QuantLlama(shape, DEV, seed=9)
+    tokens = torch.randint(0, shape.vocab, (10,), generator=torch.Generator().manual_seed(2))
+    ref = DecodeEngine(model, use_graph=False).teacher_forced_logits(tokens)
+    grp = _LockstepGroup(world)
+    engines = [DecodeEngine(model, use_graph=False, tp_group=grp.view(r)) for r in range(world)]
+    assert engines[1].P == world and engines[1].rank == 1 and engines[1].hs == shape.hidden // world
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(DEV)
+            outs[r] = engines[r].teacher_forced_logits(tokens)
+        except Exception as e:       # a dead rank must not leave the others at the barrier
+            errs.append(e)
+            grp.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert outs[r] is not None and torch.isfinite(outs[r]).all()
+        assert torch.equal(outs[r], ref), f"rank {r} of {world}"
