@@ -217,7 +217,7 @@ def prefill(model: "QuantLlama", tokens, engine=None):
     token by token; this is the batched equivalent)."""
     s = model.shape
     T = tokens.numel()
-    assert T <= s.max_seq
+    assert T <= s.max_seq and (engine is None or engine.P == 1), "prefill hands over to a single-GPU engine"
     h = model.model.embed_tokens.weight[tokens]                       # [T, hidden] fp16
     cos, sin = model.rope_cos[:T, None, :], model.rope_sin[:T, None, :]
 
@@ -258,8 +258,9 @@ class DecodeEngine:
     """One decode token = a fixed list of C-ABI launches on static buffers (hipGraph-capturable).
 
     With `tp_group` (world size P > 1) every quantized linear is row-sharded over the group (sharded.py): each rank
-    streams 1/P of the weights and one all-gather per linear (4 per layer: q|k|v, o_proj, silu(gate)*up, down_proj)
-    rebuilds the activations; everything else is replicated.
+    streams 1/P of the weights and an all-gather rebuilds the activation the next linear needs (4 per layer: attention
+    output, o_proj, silu(gate)*up, down_proj).  q|k|v needs none: a rank owns the rows of its own heads, so attention
+    and the KV caches are sharded by heads as well; norms, embedding and lm_head are replicated.
     """
 
     def __init__(self, model: QuantLlama, use_graph=True, tp_group=None):
@@ -295,22 +296,27 @@ class DecodeEngine:
         self.att = torch.zeros(s.hidden, **f16)
         self.act = torch.zeros(s.inter, **f16)
         # local (per-rank) slices; with P == 1 they alias the full buffers
+        # tensor-parallel: a rank owns the rows of q/k/v of ITS heads, so attention runs on local heads and local KV
+        # caches; what is gathered is the attention output (and h, and silu(gate)*up)
+        assert s.n_heads % P == 0 and s.n_kv_heads % P == 0, "heads must divide over the ranks"
+        self.heads_l, self.kv_heads_l = s.n_heads // P, s.n_kv_heads // P
         self.qkv_loc = torch.zeros(self.hs + 2 * self.kvs, **f16) if tp else None
-        self.qkv_all = torch.zeros(P, self.hs + 2 * self.kvs, **f16) if tp else None
+        self.att_loc = torch.zeros(self.hs, **f16) if tp else None
+        self.att_g = torch.zeros(s.hidden, **f16) if tp else None       # w3 only: o_proj input gathered by torch
         self.h_loc = torch.zeros(self.hs, **f16) if tp else None
         self.gate_loc = torch.zeros(self.its, **f16)
         self.up_loc = torch.zeros(self.its, **f16)
         self.act_loc = torch.zeros(self.its, **f16) if tp else self.act
         self.hn = torch.zeros(1, s.hidden, **f16)
         self.logits = torch.zeros(1, s.vocab, **f16)
-        self.kc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
-        self.vc = [torch.zeros(s.n_kv_heads, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
+        self.kc = [torch.zeros(self.kv_heads_l, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
+        self.vc = [torch.zeros(self.kv_heads_l, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
         # a head's context can be dealt over attn_split blocks; at the contexts benchmarked (<= 512) the merge hand-off
         # costs more than the split saves, so the default is one block per head
         self.rope_tab = torch.cat([model.rope_cos, model.rope_sin], 1).contiguous()   # [max_seq][cos 64 | sin 64]
         self.rope_row = torch.zeros(1, 128, dtype=torch.float32, device=dev)
         self.attn_split = int(os.environ.get("QEFT_ATTN_SPLIT", "1"))
-        nws = self.lib.qeft_attn_workspace_bytes(s.n_heads, self.attn_split)
+        nws = self.lib.qeft_attn_workspace_bytes(self.heads_l, self.attn_split)
         self.attn_ws = torch.zeros(nws // 4, dtype=torch.float32, device=dev) if nws else None
         self.greedy = False
         self.graph = None
@@ -385,13 +391,14 @@ class DecodeEngine:
         gemv_group = lib.qeft_gemv_w3_group if w3 else lib.qeft_gemv_w4_group
         gemv_silu = lib.qeft_gemv_w3_silu if w3 else lib.qeft_gemv_w4_silu
 
-        def gemv_fused(x, ql, ow, residual, szp, y, n, k):
-            """one linear, batch 1, + residual (no gather: the attention kernel already wrote o_proj's column order)"""
+        def gemv_fused(x, ql, ow, residual, szp, y, n, k, ids=None):
+            """one linear, batch 1, + residual.  ids: o_proj's input gather (tensor-parallel only; on one GPU the
+            attention kernel already writes o_proj's column order)"""
             if w3:
                 return lib.qeft_gemv_w3(x, ql.qweight.data_ptr(), ql.scales.data_ptr(), ql.scaled_zeros.data_ptr(), ow,
                                         None, residual, szp, y, 1, n, k, g, no, st)
             return lib.qeft_gemv_w4_fused(x, ql.qweight.data_ptr(), ql.scales.data_ptr(), ql.scaled_zeros.data_ptr(), ow,
-                                          None, None, residual, szp, y, 1, n, k, g, no, st)
+                                          None, ids, residual, szp, y, 1, n, k, g, no, st)
 
         def pick(tag, fn):      # per-kernel timing (bench.py): keep one GEMV of the layer, drop the others
             return fn if only in (None, tag) else (lambda *a: 0)
@@ -414,25 +421,39 @@ class DecodeEngine:
             qw, sc, sz, ow, ys, ns, szp = pk["qkv"]
             ck(group_qkv(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
                          s.hidden, g, no, st))
-            if tp:
-                self._all_gather(self.qkv_all.view(-1), self.qkv_loc)
-                self.q.view(P, self.hs).copy_(self.qkv_all[:, :self.hs])
-                self.k.view(P, self.kvs).copy_(self.qkv_all[:, self.hs:self.hs + self.kvs])
-                self.v.view(P, self.kvs).copy_(self.qkv_all[:, self.hs + self.kvs:])
             if not linears_only:
-                ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
-                                             self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
-                                             self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
-                                             self.att_pos[li].data_ptr() if self.att_pos[li] is not None else None,
-                                             self.att.data_ptr(), self.attn_ws.data_ptr() if self.attn_ws is not None else None,
-                                             self.attn_split, s.n_heads, s.n_kv_heads, s.max_seq, st))
+                if tp:      # local heads only: q/k/v slices straight from the grouped GEMV, natural output order
+                    qp = self.qkv_loc.data_ptr()
+                    ck(lib.qeft_rope_attn_decode(qp, qp + self.hs * 2, qp + (self.hs + self.kvs) * 2,
+                                                 self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
+                                                 self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(), None,
+                                                 self.att_loc.data_ptr(),
+                                                 self.attn_ws.data_ptr() if self.attn_ws is not None else None,
+                                                 self.attn_split, self.heads_l, self.kv_heads_l, s.max_seq, st))
+                else:
+                    ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
+                                                 self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
+                                                 self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                                 self.att_pos[li].data_ptr() if self.att_pos[li] is not None else None,
+                                                 self.att.data_ptr(),
+                                                 self.attn_ws.data_ptr() if self.attn_ws is not None else None,
+                                                 self.attn_split, s.n_heads, s.n_kv_heads, s.max_seq, st))
+            if tp:
+                self._all_gather(self.att, self.att_loc)      # natural head order (ranks own consecutive heads)
             o = lin["o"]
             ow_o = o.oweight_interleaved.data_ptr() if no else None
             szp_o = o._szp(o.scales)
             szp_o = szp_o.data_ptr() if szp_o is not None else None
             if tp:
-                ck(fused_o(self.att.data_ptr(), o, ow_o, h[r0:r0 + self.hs].data_ptr(), szp_o, self.h_loc.data_ptr(),
-                           self.hs, s.hidden))
+                ids32 = getattr(o, "reorder_ids32", None)
+                if ids32 is not None and w3:                   # the 3-bit GEMV has no gather: torch does it
+                    torch.index_select(self.att, 0, o.reorder_ids, out=self.att_g)
+                    ids32 = None
+                    xin = self.att_g
+                else:
+                    xin = self.att
+                ck(fused_o(xin.data_ptr(), o, ow_o, h[r0:r0 + self.hs].data_ptr(), szp_o, self.h_loc.data_ptr(),
+                           self.hs, s.hidden, ids32.data_ptr() if ids32 is not None else None))
                 self._all_gather(h2, self.h_loc)
                 h, h2 = h2, h
             else:
