@@ -161,10 +161,11 @@ def main():
     if graph_ok:
         try:
             eng.capture()
+            eng.precapture(args.warmup + args.steps + 1)     # one graph per attention split the run will reach
         except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            eng.use_graph, eng.graph, graph_ok = False, None, False
+            eng.use_graph, eng.graph, eng.graphs, graph_ok = False, None, {}, False
             torch.cuda.synchronize(dev)
 
     # ---- warm-up: W tokens (they also build the KV-cache context, cf. benchmark.py ctx 64)

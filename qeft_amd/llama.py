@@ -243,7 +243,7 @@ def prefill(model: "QuantLlama", tokens, engine=None):
         x = _rmsnorm(h, L.post_attention_layernorm, s.rms_eps)
         h = h + mlp.down_proj(_silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
     if engine is not None:
-        engine.pos.fill_(T)
+        engine.set_position(T)
     return torch.matmul(_rmsnorm(h, model.model.norm, s.rms_eps), model.lm_head.weight.t())
 
 
@@ -311,13 +311,20 @@ class DecodeEngine:
         self.logits = torch.zeros(1, s.vocab, **f16)
         self.kc = [torch.zeros(self.kv_heads_l, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
         self.vc = [torch.zeros(self.kv_heads_l, s.max_seq, s.head_dim, **f16) for _ in range(s.n_layers)]
-        # a head's context can be dealt over attn_split blocks; at the contexts benchmarked (<= 512) the merge hand-off
-        # costs more than the split saves, so the default is one block per head
+        # A head's context is dealt over attn_split blocks.  One CU pulls ~50 GB/s, so past a few hundred cached positions
+        # one block per head is bound by its own fetch; below that the merge hand-off (~2.5 us) costs more than the split
+        # saves.  Measured on Llama-2-7B: contexts 64..192 -> 653 / 641 / 638 tokens/s at split 1 / 2 / 4; 100..700 ->
+        # 604 / 624 / 631 / 611 at 1 / 2 / 4 / 8; 500..2000 -> 435 vs 570 at 1 vs 4.  The split follows the position
+        # (one captured graph per split); QEFT_ATTN_SPLIT pins it.
         self.rope_tab = torch.cat([model.rope_cos, model.rope_sin], 1).contiguous()   # [max_seq][cos 64 | sin 64]
         self.rope_row = torch.zeros(1, 128, dtype=torch.float32, device=dev)
-        self.attn_split = int(os.environ.get("QEFT_ATTN_SPLIT", "1"))
-        nws = self.lib.qeft_attn_workspace_bytes(self.heads_l, self.attn_split)
-        self.attn_ws = torch.zeros(nws // 4, dtype=torch.float32, device=dev) if nws else None
+        forced = os.environ.get("QEFT_ATTN_SPLIT")
+        self.attn_split_forced = int(forced) if forced else None
+        self.attn_split = self.attn_split_forced or 1
+        nws = self.lib.qeft_attn_workspace_bytes(self.heads_l, 8)
+        self.attn_ws = torch.zeros(nws // 4, dtype=torch.float32, device=dev)
+        self.host_pos = 0          # host mirror of self.pos (chooses the split; any split is correct at any position)
+        self.graphs = {}
         self.greedy = False
         self.graph = None
         self.use_graph = use_graph
@@ -369,8 +376,18 @@ class DecodeEngine:
             import torch.distributed as dist
             dist.all_gather_into_tensor(out, inp, group=self.tp_group)
 
+    def _split_for(self, pos):
+        if self.attn_split_forced:
+            return self.attn_split_forced
+        return 1 if pos < 256 else (4 if pos < 1536 else 8)
+
     def reset(self):
-        self.pos.zero_()
+        self.set_position(0)
+
+    def set_position(self, t):
+        """The next token to be fed sits at position t (the KV caches hold positions < t)."""
+        self.pos.fill_(t)
+        self.host_pos = int(t)
 
     def weight_bytes_per_token(self):
         """Algorithmic HBM bytes of the quantized linears one token streams on THIS rank (SURVEY.md §8d formula)."""
@@ -489,8 +506,10 @@ class DecodeEngine:
         ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
                               1 if self.greedy else 0, st))
 
-    def capture(self, linears_only=False, only=None):
-        """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires)."""
+    def capture(self, linears_only=False, only=None, split=None):
+        """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires).  `split`:
+        attention blocks per head baked into this graph (default: what the current position asks for)."""
+        self.attn_split = split or self._split_for(self.host_pos)
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         pos0, tok0 = self.pos.clone(), self.tok.clone()
@@ -507,17 +526,29 @@ class DecodeEngine:
         self.tok.copy_(tok0)
         if linears_only:
             return graph
-        self.graph = graph
+        self.graph = self.graphs[self.attn_split] = graph
         return graph
+
+    def precapture(self, max_pos):
+        """Capture the graphs of every attention split the positions [host_pos, max_pos) will use (so that none is
+        captured inside a timed region)."""
+        for sp in sorted({self._split_for(p) for p in (self.host_pos, 255, 256, 1535, 1536, max_pos - 1)
+                          if self.host_pos <= p < max_pos}):
+            if sp not in self.graphs:
+                self.capture(split=sp)
 
     def step(self):
         """Run one token: consumes self.tok at position self.pos, leaves logits (and, if greedy, the next token)."""
+        sp = self._split_for(self.host_pos)
         if self.use_graph:
-            if self.graph is None:
-                self.capture()
-            self.graph.replay()
+            g = self.graphs.get(sp)
+            if g is None:
+                g = self.capture(split=sp)
+            g.replay()
         else:
+            self.attn_split = sp
             self._launch_token()
+        self.host_pos += 1
 
     @torch.no_grad()
     def teacher_forced_logits(self, tokens):

@@ -330,3 +330,22 @@ def test_prefill_matches_dense_model_and_hands_over_to_decode():
     torch.cuda.synchronize()
     assert (cont - full).abs().max().item() / full.abs().max().item() < 2e-2
     assert (cont.argmax(-1) == full.argmax(-1)).float().mean().item() >= 0.8
+
+
+def test_attention_split_follows_the_position():
+    """Past 256 cached positions the engine switches to 4 attention blocks per head (its own captured graph); logits
+    stay within tolerance of the one-block-per-head run and the switch happens where it should."""
+    from qeft_amd.llama import DecodeEngine, QuantLlama, tiny_shape
+    shape = tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=384, max_seq=320)
+    model = QuantLlama(shape, DEV, seed=8)
+    tokens = torch.randint(0, shape.vocab, (300,), generator=torch.Generator().manual_seed(5))
+    eng = DecodeEngine(model, use_graph=True)
+    assert [eng._split_for(p) for p in (0, 255, 256, 1535, 1536)] == [1, 1, 4, 4, 8]
+    got = eng.teacher_forced_logits(tokens)
+    assert sorted(eng.graphs) == [1, 4] and eng.host_pos == 300
+    one = DecodeEngine(model, use_graph=False)
+    one.attn_split_forced = 1
+    ref = one.teacher_forced_logits(tokens)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:256], ref[:256])                       # same kernels, same order before the switch
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 5e-3

@@ -12,9 +12,7 @@ model = QuantLlama(shape, dev, seed=0, fast_init=True)
 eng = DecodeEngine(model, use_graph=False)
 eng.greedy = True
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-eng.attn_split = S
-nws = _lib.lib().qeft_attn_workspace_bytes(32, S)
-eng.attn_ws = torch.zeros(max(nws // 4, 4), dtype=torch.float32, device=dev)
+eng.attn_split_forced = S
 lib = _lib.lib()
 lib.qeft_debug_attn_stamps.argtypes = [ctypes.c_void_p]
 lib.qeft_debug_attn_stamps.restype = None
