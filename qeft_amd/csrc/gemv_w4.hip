@@ -1,25 +1,19 @@
-// Decode GEMV for the QEFT packed W4 (+ fp16 outlier slice) linear on gfx950.
+// Decode GEMV for the QEFT packed W4 (+ fp16 outlier slice) linear on gfx950: launch logic.
 //
 // Replaces gemv_kernel / gemv_kernel_qeft (+ perchannel twins) of
-// qeft/kernel/quantization_new/gemv/gemv_cuda{,_qeft}.cu.  Not a translation: the
-// reference tiles for 32-wide warps (8 rows x 2048 k per 256-thread block, fp16
-// accumulation); this kernel is laid out for 64-wide wavefronts and HBM streaming:
+// qeft/kernel/quantization_new/gemv/gemv_cuda{,_qeft}.cu.  Not a translation: the reference tiles for 32-wide warps
+// (8 rows x 2048 k per 256-thread block, fp16 accumulation).  Two device implementations live in headers:
 //
-//  * The checkpoint stores 4 output rows interleaved per 64-k tile, i.e. one row-group
-//    (4 rows) is ONE contiguous stream of 2K bytes.  A wave-wide 16 B/lane load covers
-//    1 KiB = 4 rows x 512 k, perfectly coalesced; lane l owns row (l>>1)&3 and the 32 k
-//    starting at (l>>3)*64 + (l&1)*32 of that 512-k step.
-//  * A 256-thread block owns RG row-groups (4*RG rows).  Its 4 waves split K by 512-k
-//    steps (wave w takes steps w, w+4, ...), so the x slice a lane loads (64 B per batch
-//    row) is reused in registers for all RG row-groups and never crosses waves: no LDS
-//    staging and no barrier in front of the dot.  Loads go straight to VGPRs and the next
-//    step's loads are issued before the current step's math (guide: "GEMV / M <= 16").
-//  * fp16 dequant is bit-identical to the reference (one rounded FMA per weight), the dot
-//    accumulates in fp32 with v_dot2c_f32_f16, lanes sharing a row are combined with
-//    4 xor-shuffles, the 4 waves through 1.8 KB of LDS.
-//  * The fp16 outlier slice replaces the dead nibbles of the last n_out columns: lanes
-//    whose 32-k chunk lies there skip the INT4 load and read 128 B of oweight_interleaved.
-//  * Optional fusions (qeft_gemv_w4_fused): o_proj input gather through LDS, bias, residual.
+//  * gemv_w4_mfma.h   the production path (K % 128 == 0, n_out % 128 == 0, group 128 or per-channel, N % 16 == 0): one
+//                     wave-wide 16 B/lane load = 16 rows x 128 k = the B operand of v_mfma_f32_16x16x32_f16; x, the
+//                     scale shadow and the de-interleaved outlier slab staged in LDS once per long-lived block; fused
+//                     gather / RMSNorm / SiLU*up / bias / residual; 1..16 batch rows per weight pass.
+//  * gemv_w4_kernel.h the first (VALU, v_dot2c) formulation, kept for everything the MFMA path does not take: other
+//                     group sizes, n_out in {32, 64, 96}, ragged N.  Bit-identical fp16 dequantisation to the
+//                     reference (one rounded FMA per weight), fp32 accumulation.
+//
+// This file picks the kernel, the grid (row sets per block, XCD-contiguous) and the ring depth, slices a batch that
+// does not fit the LDS, and assembles the grouped (q|k|v, gate|up) launches.
 #include <cstdlib>
 
 #include "gemv_w4_mfma.h"
@@ -127,7 +121,7 @@ static hipError_t launch_mfma_m(const GemvArgs& a, int m, hipStream_t st) {
     }
 }
 
-// ring depth (steps in flight per wave), measured with tools/gemv_lab.hip: short rows want 2, long rows 6
+// ring depth (steps in flight per wave), measured with tools/gemv_lab.hip and bench.py: 4, 6 for K > 6144; deeper is slower
 static int mfma_depth(int K);
 // Small-M route of the GEMM entry (8 <= M <= ~128): the MFMA GEMV contracts up to 16 batch rows per pass at the
 // cost of one weight stream, far cheaper than a 128-row GEMM tile at these sizes.  Processes rows in slices of <= 16.

@@ -126,7 +126,7 @@ void timeline(std::vector<Layer>& Ls, void* x, void* y, int N, int K, int nblk) 
         CK(hipMemcpy(h2.data(), dbg2, h2.size() * 8, hipMemcpyDeviceToHost));
         std::vector<double> q[4];
         for (size_t i = 0; i < h2.size(); i += 4) for (int p = 0; p < 4; ++p) q[p].push_back((double)(long long)h2[i + p]);
-        printf("    stage detail (median cycles): wait-x+sumsq %.0f | reduce+normalise %.0f | staging writes %.0f | barrier %.0f\n", med(q[0]), med(q[1]), med(q[2]), med(q[3]));
+        printf("    stage detail (median cycles): x arrives + sum of squares %.0f | x*gamma %.0f | staging writes %.0f | barrier %.0f\n", med(q[0]), med(q[1]), med(q[2]), med(q[3]));
     }
     CK(hipFree(dbg)); CK(hipFree(dbg2));
 }
