@@ -5,6 +5,8 @@
 //              y = x * rsqrt(mean(x^2) + eps) * gamma, one rounding to fp16.
 //   attention  reference: qeft/kernel/attention (vendored FT masked MHA, ft_attention.cpp:110-181): rotary
 //              (neox style = HF rotate_half), append k/v at `timestep`, softmax(q.K^T/sqrt(d)).V.
+#include <cstdlib>
+
 #include "qeft_common.h"
 
 namespace qeft {
@@ -116,7 +118,10 @@ constexpr int kAttnRec = 132;   // floats per (head, split) record of the worksp
 //   * S > 1: every block publishes its (acc, max, sum) record with write-through stores and takes a ticket from the
 //     head's counter; the block that draws the last ticket merges the S records in split order (deterministic) and
 //     re-arms the counter.  Nobody waits for anybody (MI355X_MICROARCH.md, inter-workgroup visibility, table row 1).
-template <int PRE>
+// DH = 2 (one block per head only): the head's 128 output dims are dealt over DH blocks.  Both compute the scores (K is
+// fetched twice), each fetches half of every V row and does half of P.V; their outputs are disjoint, so there is nothing
+// to merge.  Per block 3/4 of the bytes (the bound at these sizes is what ONE CU can pull) and half of the P.V math.
+template <int PRE, int DH = 1>
 __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ v, const float* __restrict__ cs,
                                                                const float* __restrict__ sn, f16* __restrict__ kc,
@@ -134,26 +139,32 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     mark(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     float* prob = (float*)smem_raw;          // [max_seq + 16] raw scores
-    float* part = prob + max_seq + 16;       // [16][128] P.V partials: (wave, position class)
-    float* psum = part + 16 * HD;            // [16] exp sums
-    float* wm = psum + 16;                   // [4] wave maxima
+    float* part = prob + max_seq + 16;       // [16*DH][128/DH] P.V partials: (wave, position class) x dims of this block
+    float* psum = part + 16 * HD;            // [16*DH] exp sums
+    float* wm = psum + 64;                   // [4] wave maxima
     f16* knew = (f16*)(wm + 4);              // [128]
     f16* vnew = knew + HD;                   // [128]
     f16* qs = vnew + HD;                     // [128] rotated, pre-scaled q (fp16 like the reference's rotated q)
     __shared__ int last_ticket;
 
-    const int h = blockIdx.x / S, sp = blockIdx.x % S, t = threadIdx.x, lane = t & 63;
+    constexpr int HDB = HD / DH;             // output dims of this block
+    constexpr int NDG = 16 / DH;             // 8-dim groups of this block
+    constexpr int NPC = 64 / NDG;            // position classes of a 16-position run
+    constexpr int PPC = 16 / NPC;            // positions per class
+    const int dhi = (int)(blockIdx.x % DH);
+    const int hs_idx = blockIdx.x / DH;
+    const int h = hs_idx / S, sp = hs_idx % S, t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int gw = sp * 4 + w, NW = 4 * S;   // this wave among the head's waves
     const int grp = n_heads / n_kv, hk = h / grp;
     f16* kch = kc + (size_t)hk * max_seq * HD;
     f16* vch = vc + (size_t)hk * max_seq * HD;
-    const bool appender = (sp == 0) && (h % grp == 0);
+    const bool appender = (sp == 0) && (dhi == 0) && (h % grp == 0);
 
     // ---- loads that do not depend on pos.  All of them are unconditional (addresses selected, never branched on)
     // and nothing is converted here: a conversion or a divergent branch makes the compiler wait for the load on the
     // spot, which serialises one memory round trip per load group at the top of the kernel.
-    const int ti = t & 127;
+    const int ti = dhi * HDB + (t & (HDB - 1));                        // output element of this thread (within the head)
     const int* opp = out_pos ? out_pos + h * HD + ti : pos_ptr;        // dummy in-range address when there is no map
     const int opos_raw = *opp;
     const f16* src = (t < 64) ? q + h * HD + t : (t < 128) ? k + hk * HD + (t - 64) : v + hk * HD + (t - 128);
@@ -176,8 +187,10 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     // score role: position pj of the run, dims qd*8 + 32*j .. +8 (j = 0..3): the 4 lanes of a position read 64
     // contiguous bytes per load instruction
     const int qd = lane & 3, pj = lane >> 2;
-    const int dg = lane & 15, pc = lane >> 4;    // P.V role: dims dg*8.., positions pc*4 .. pc*4+3 of the run
-    h8 kpre[PRE][4], vpre[PRE][4];
+    // P.V role: dims dhi*HDB + dg*8 .., positions pc*PPC .. of the run
+    const int dg = lane & (NDG - 1), pc = lane / NDG;
+    const int dim0 = dhi * HDB + dg * 8;
+    h8 kpre[PRE][4], vpre[PRE][PPC];
 #pragma unroll
     for (int i = 0; i < PRE; ++i) {
         const int r0 = (i * NW + gw) * 16;                      // max_seq % 16 == 0: a run never straddles the cache end
@@ -189,10 +202,10 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
 #pragma unroll
     for (int i = 0; i < PRE; ++i) {
         const int r0 = (i * NW + gw) * 16;
-        const int vrow = r0 < L ? r0 + pc * 4 : 0;
-        const h8* row = (const h8*)(vch + (size_t)vrow * HD + dg * 8);
+        const int vrow = r0 < L ? r0 + pc * PPC : 0;
+        const h8* row = (const h8*)(vch + (size_t)vrow * HD + dim0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vpre[i][j] = row[j * (HD / 8)];
+        for (int j = 0; j < PPC; ++j) vpre[i][j] = row[j * (HD / 8)];
     }
     const int opos = out_pos ? opos_raw : h * HD + ti;
     const float ra = (float)raw_a, rb = (float)raw_b;
@@ -270,15 +283,17 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
     float lsum = 0.f;
     auto pv_run = [&](int i, const h8* vr) {
-        const int p0 = (i * NW + gw) * 16 + pc * 4;
-        const f32x4 sraw = *(const f32x4*)(prob + p0);
+        const int p0 = (i * NW + gw) * 16 + pc * PPC;
+        float sraw[PPC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PPC; ++j) sraw[j] = prob[p0 + j];
+#pragma unroll
+        for (int j = 0; j < PPC; ++j) {
             const int p = p0 + j;
             if (p < L) {
                 const float e = __expf(sraw[j] - mw);
                 h8 vv = vr[j];
-                if (p == pos) vv = *(const h8*)(vnew + dg * 8);
+                if (p == pos) vv = *(const h8*)(vnew + dim0);
                 lsum += e;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) o[d] += e * (float)vv[d];
@@ -289,17 +304,17 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     for (int i = 0; i < PRE; ++i)
         if ((i * NW + gw) * 16 < L) pv_run(i, vpre[i]);
     for (int i = PRE; (i * NW + gw) * 16 < L; ++i) {
-        h8 vr[4];
+        h8 vr[PPC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            vr[j] = *(const h8*)(vch + (size_t)((i * NW + gw) * 16 + pc * 4 + j) * HD + dg * 8);
+        for (int j = 0; j < PPC; ++j)
+            vr[j] = *(const h8*)(vch + (size_t)((i * NW + gw) * 16 + pc * PPC + j) * HD + dim0);
         pv_run(i, vr);
     }
     {
-        float* dst = part + (w * 4 + pc) * HD + dg * 8;
+        float* dst = part + (w * NPC + pc) * HDB + dg * 8;
         *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4*)(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
-        if (dg == 0) psum[w * 4 + pc] = lsum;
+        if (dg == 0) psum[w * NPC + pc] = lsum;
         if (lane == 0) wm[w] = mw;
     }
     mark(5);
@@ -308,16 +323,16 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     // ---- merge the block's 4 waves (a wave without positions has max -3e38: factor 0)
     const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
     float acc = 0.f, den = 0.f;
-    if (t < HD) {
+    if (t < HDB) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float f = __expf(wm[g >> 2] - M);
-            acc += f * part[g * HD + t];
+        for (int g = 0; g < 4 * NPC; ++g) {
+            const float f = __expf(wm[g / NPC] - M);
+            acc += f * part[g * HDB + t];
             den += f * psum[g];
         }
     }
     if (S == 1) {
-        if (t < HD) out[opos] = (f16)(acc / den);
+        if (t < HDB) out[opos] = (f16)(acc / den);
         if (dbg && lane == 0) {
             mark(7);
             unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + w) * 12;
@@ -457,18 +472,25 @@ size_t attn_workspace_bytes(int n_heads, int S) { return S > 1 ? ((size_t)n_head
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
                                    void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
                                    int n_kv, int max_seq, int S, int tab_rows, hipStream_t st) {
-    const size_t smem = (size_t)(max_seq + 16) * 4 + 16 * 128 * 4 + 16 * 4 + 4 * 4 + 3 * 128 * 2;
+    const size_t smem = (size_t)(max_seq + 16) * 4 + 16 * 128 * 4 + 64 * 4 + 4 * 4 + 3 * 128 * 2;
     // prefetch 256 positions per head whatever the split: PRE runs of 16 on each of the 4*S waves
+    int dh = 1;
     auto launch = [&](auto kern) -> hipError_t {
         if (smem > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(n_heads * S), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v,
+        hipLaunchKernelGGL(kern, dim3(n_heads * S * dh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v,
                            (const float*)cs, (const float*)sn, (f16*)kc, (f16*)vc, pos, out_pos, (f16*)out, (float*)ws,
                            n_heads, n_kv, max_seq, S, tab_rows, g_attn_dbg);
         return hipGetLastError();
     };
+    // measured on the 7B decode step (contexts 64..192): 682 / 689 / 688 tokens/s with 1 / 2 / 4 blocks per head
+    static const int dh_env = getenv("QEFT_ATTN_DH") ? atoi(getenv("QEFT_ATTN_DH")) : 2;   // A/B switch: 1 or 2
+    if (S == 1 && dh_env == 2) {
+        dh = 2;
+        return launch(rope_attn_decode_kernel<4, 2>);
+    }
     if (S == 1) return launch(rope_attn_decode_kernel<4>);
     if (S == 2) return launch(rope_attn_decode_kernel<2>);
     return launch(rope_attn_decode_kernel<1>);

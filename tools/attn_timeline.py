@@ -16,7 +16,7 @@ eng.attn_split_forced = S
 lib = _lib.lib()
 lib.qeft_debug_attn_stamps.argtypes = [ctypes.c_void_p]
 lib.qeft_debug_attn_stamps.restype = None
-dbg = torch.zeros(32 * S * 4 * 12, dtype=torch.int64, device=dev)
+dbg = torch.zeros(128 * S * 4 * 12, dtype=torch.int64, device=dev)   # up to 4 blocks per (head, split)
 eng.reset(); eng.tok.fill_(1)
 for _ in range(150):
     eng.step()
@@ -25,7 +25,8 @@ for _ in range(3):
     eng.step()
 torch.cuda.synchronize()
 lib.qeft_debug_attn_stamps(None)
-d = dbg.view(32 * S, 4, 12).cpu().double()
+d = dbg.view(128 * S, 4, 12).cpu().double()
+d = d[d[:, 0, 1] > 0]                      # blocks that ran
 rt = (d[..., 1] - d[..., 0]) * 10.0      # ns (100 MHz)
 cyc = (d[..., 9] if S == 1 else d[..., 10]) - d[..., 2]
 print("ns per wave (realtime) mean %.0f  max %.0f ; cycles mean %.0f -> %.2f GHz" % (rt.mean(), rt.max(), cyc.mean(), cyc.mean() / rt.mean()))
