@@ -262,13 +262,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
         szl[i] = sv | (zv << 16);
     }
 
-    // ---- DMA sources.  A: wave w, instruction i -> rows (w*4+i)*8 + lane/8, slot' = lane%8 holds chunk slot'^(row&7)
+    // ---- DMA sources.  A: wave w, instruction i -> rows (w*4+i)*8 + lane/8, slot' = lane%8 holds chunk slot'^((row>>1)&7)
     const f16* asrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int grow = min(bm0 + row, M - 1);
-        asrc[i] = x + (size_t)grow * K + (((lane & 7) ^ (row & 7)) << 3);
+        asrc[i] = x + (size_t)grow * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
     }
     const int brg = min(bn0 / 4 + (tid >> 3), N / 4 - 1);
     const uint8_t* bsrc = qw + (size_t)brg * K * 2 + (tid & 7) * 16;
@@ -292,7 +292,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     // per-lane LDS offsets of the A fragments: m-tile mt, k-step j -> row*128 + ((h*4+j) ^ (row&7))*16
     uint32_t aoff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ (r & 7)) << 4));   // (row & 7) == (r & 7): mt*32 keeps the low bits
+    // swizzle by (row >> 1) & 7: 128-byte rows put two rows in one 64-bank period, so the 16 lanes of a ds_read_b128 group
+    // (rows r .. r+15) hit 8 even and 8 odd rows -- the 8 rows of one parity need 8 different slots (SQ_LDS_BANK_CONFLICT
+    // was 49 % of the LDS cycles with the (row & 7) swizzle, which repeats after 8 rows)
+    for (int j = 0; j < 4; ++j) aoff[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));   // mt*32 rows keep (row >> 1) & 7
     const uint32_t boff = (uint32_t)(BM * BK * 2 + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);
     const uint32_t szoff = (uint32_t)(kStages * kTileBytes + nloc * 4);
 
