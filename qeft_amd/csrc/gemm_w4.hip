@@ -188,7 +188,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel(const f16* __rest
 constexpr int kStages = 3;
 constexpr int kTileBytes = BM * BK * 2 + BN * BK / 2;   // 16 KB of A + 4 KB of packed B
 
-__host__ __device__ constexpr size_t gemm_v2_smem(int K, int G) { return (size_t)kStages * kTileBytes + (size_t)(K / G) * BN * 4; }
+__host__ __device__ constexpr size_t gemm_v2_smem(int K, int G, int nwv = 4) {
+    return (size_t)kStages * (BM * BK * 2 + 32 * nwv * BK / 2) + (size_t)(K / G) * 32 * nwv * 4;
+}
 
 // LDS reads of DMA-written tiles go through inline asm: hipcc (ROCm 7.2) otherwise drains the whole DMA pipeline with
 // s_waitcnt vmcnt(0) before any ds_read that might alias an LDS-DMA in flight.  The loads are made visible to the
@@ -218,14 +220,18 @@ __device__ __forceinline__ void lds_wait() {
 __device__ __forceinline__ void wait_vm(int n) {   // counted wait: n outstanding vector-memory ops allowed
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
     }
 }
 
-template <bool OUTL>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
+// NWV waves side by side in N, each 128 x 32: block tile 128 x (32 NWV).  NWV = 8 (128 x 256) reads the activation tile
+// once for twice the columns: 24 KB per 4.2 MFLOP instead of 20 KB per 2.1 (the GEMM is bound by the L2/MALL ->
+// LDS traffic of the activation tiles, the packed weights are tiny).
+template <bool OUTL, int NWV>
+__global__ __launch_bounds__(64 * NWV) void gemm_w4_kernel_v2(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                                   const f16* __restrict__ scales,
                                                                   const f16* __restrict__ zeros,
                                                                   const f16* __restrict__ ow, const f16* __restrict__ bias,
@@ -235,8 +241,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     // request latency): block z contracts its share of the INT4 k-tiles (the last one also the fp16 tiles) and writes
     // an fp32 partial tile to part[z][M][N]; gemm_splitk_reduce_kernel sums the S partials in order, adds the bias
     // and rounds once.
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];     // [kStages][A 16 KB | B 4 KB] [sz]
-    uint32_t* szl = (uint32_t*)(lds + kStages * kTileBytes);          // [K/G][128]
+    constexpr int BN = 32 * NWV, GEMM_THREADS = 64 * NWV;             // (shadow the file-level 128-wide constants)
+    constexpr int kTileBytes = BM * BK * 2 + BN * BK / 2;             // 16 KB of A + NWV KB of packed B
+    constexpr int kAI = 16 / NWV;                                     // A-tile DMA instructions per wave (1 KB each)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];     // [kStages][A 16 KB | B NWV KB] [sz]
+    uint32_t* szl = (uint32_t*)(lds + kStages * kTileBytes);          // [K/G][BN]
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;                   // LDS byte address of the array (for the asm reads)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -263,10 +272,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     }
 
     // ---- DMA sources.  A: wave w, instruction i -> rows (w*4+i)*8 + lane/8, slot' = lane%8 holds chunk slot'^((row>>1)&7)
-    const f16* asrc[4];
+    const f16* asrc[kAI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < kAI; ++i) {
+        const int row = (wave * kAI + i) * 8 + (lane >> 3);
         const int grow = min(bm0 + row, M - 1);
         asrc[i] = x + (size_t)grow * K + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
     }
@@ -276,9 +285,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     auto stage = [&](int t) {
         uint8_t* base = lds + (t % kStages) * kTileBytes;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < kAI; ++i)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[i] + (size_t)t * BK),
-                                             (void __attribute__((address_space(3)))*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+                                             (void __attribute__((address_space(3)))*)(base + (wave * kAI + i) * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(bsrc + (size_t)min(t, qtiles > 0 ? qtiles - 1 : 0) * 128),
                                          (void __attribute__((address_space(3)))*)(base + BM * BK * 2 + wave * 1024), 16, 0, 0);
     };
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
     // ---- main loop over the INT4 k-tiles: kStages-1 tiles in flight, one barrier per tile
     for (int t = kt0; t < kt1; ++t) {
         const int younger = min(kt1 - 1 - t, kStages - 2);
-        wait_vm(younger * 5);
+        wait_vm(younger * (kAI + 1));
         __builtin_amdgcn_s_barrier();      // every wave's DMA for tile t landed; everyone is done reading tile t-1
         if (t + kStages - 1 < kt1) stage(t + kStages - 1);   // overwrites the buffer of tile t-1
 
@@ -361,9 +370,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_w4_kernel_v2(const f16* __r
             __builtin_amdgcn_s_barrier();          // all waves finished reading the buffers of earlier tiles
             uint8_t* base = lds;                   // stage buffer 0
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < kAI; ++i)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(asrc[i] + (size_t)t * BK),
-                                                 (void __attribute__((address_space(3)))*)(base + (wave * 4 + i) * 1024), 16, 0, 0);
+                                                 (void __attribute__((address_space(3)))*)(base + (wave * kAI + i) * 1024), 16, 0, 0);
             u32x4 bfrag[4];
             const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + (t * BK + h * 32 - kq));
 #pragma unroll
@@ -428,29 +437,37 @@ int gemm_w4_split(int M, int N, int K, int n_out) {
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
                           void* workspace, size_t workspace_bytes) {
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    int S = workspace ? gemm_w4_split(M, N, K, (ow && n_out > 0) ? n_out : 0) : 1;
+    const bool outl = ow && n_out > 0;
+    // 128 x 256 tiles (8 waves) when they still give every CU a block: always a gain where the 128 x 128 kernel's scale
+    // array leaves room for one block per CU only (K = 11008: 747 -> 945 TFLOP/s at M = 2048), a few % otherwise at
+    // M >= 2048; smaller problems keep the 128 x 128 tile (more blocks).  QEFT_GEMM_NWV = 4 / 8 forces one (A/B).
+    static const int force_nwv = getenv("QEFT_GEMM_NWV") ? atoi(getenv("QEFT_GEMM_NWV")) : 0;
+    int nwv = 4;
+    const bool one_block4 = gemm_v2_smem(K, G, 4) > 80 * 1024;
+    if (force_nwv == 8 || (force_nwv == 0 && N % 256 == 0 && ((M + BM - 1) / BM) * (N / 256) >= 256 && (one_block4 || M >= 2048)))
+        nwv = 8;
+    if (gemm_v2_smem(K, G, nwv) > 160 * 1024) nwv = 4;
+    const int bn = 32 * nwv;
+    dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn);
+    int S = workspace ? gemm_w4_split(M, N, K, outl ? n_out : 0) : 1;
+    if (nwv == 8) S = 1;
     while (S > 1 && (size_t)S * M * N * 4 > workspace_bytes) --S;
     if (N % 4 != 0) S = 1;
-    const bool outl = ow && n_out > 0;
-    const size_t smem2 = gemm_v2_smem(K, G);
+    const size_t smem2 = gemm_v2_smem(K, G, nwv);
     if (K / BK >= kStages && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && smem2 <= 160 * 1024 &&
         getenv("QEFT_GEMM_V1") == nullptr) {
-        if (outl) {
-            auto kern = gemm_w4_kernel_v2<true>;
+        auto go = [&](auto kern) -> hipError_t {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(grid.x, grid.y, S), dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw,
-                               (const f16*)scales, (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G,
-                               n_out, (float*)workspace);
-        } else {
-            auto kern = gemm_w4_kernel_v2<false>;
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(grid.x, grid.y, S), dim3(GEMM_THREADS), smem2, st, (const f16*)x, (const uint8_t*)qw,
-                               (const f16*)scales, (const f16*)zeros, (const f16*)nullptr, (const f16*)bias, (f16*)y, M, N, K, G,
-                               0, (float*)workspace);
-        }
+            hipLaunchKernelGGL(kern, dim3(grid.x, grid.y, S), dim3(64 * nwv), smem2, st, (const f16*)x, (const uint8_t*)qw,
+                               (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
+                               (f16*)y, M, N, K, G, outl ? n_out : 0, (float*)workspace);
+            return hipGetLastError();
+        };
+        hipError_t e;
+        if (nwv == 8) e = outl ? go(gemm_w4_kernel_v2<true, 8>) : go(gemm_w4_kernel_v2<false, 8>);
+        else e = outl ? go(gemm_w4_kernel_v2<true, 4>) : go(gemm_w4_kernel_v2<false, 4>);
+        if (e != hipSuccess) return e;
         if (S > 1) {
             const size_t quads = (size_t)M * N / 4;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, st,
@@ -458,6 +475,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         }
         return hipGetLastError();
     }
+    grid = dim3((M + BM - 1) / BM, (N + BN - 1) / BN);
     if (ow && n_out > 0)
         hipLaunchKernelGGL(gemm_w4_kernel<true>, grid, dim3(GEMM_THREADS), 0, st, (const f16*)x, (const uint8_t*)qw,
                            (const f16*)scales, (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G,
