@@ -43,6 +43,10 @@ typedef void* qeft_stream_t;
 int qeft_abi_version(void);
 const char* qeft_error_string(int code);
 int qeft_last_hip_error(void);
+/* Name of the kernel variant the calling thread's most recent compute entry point launched, e.g. "gemv_mfma",
+ * "gemm_v2_128x256", "gemm_v2_128x128+splitk", "gemv_smallm", "dx128", "dx64+split", "grad_oweight_mfma".  Static storage;
+ * diagnostic only (the parity tests assert it so that every routing tier keeps its coverage). */
+const char* qeft_last_variant(void);
 
 /* Decode GEMV, m in 1..7, no outlier slice.
  * Replaces gemv_4bit(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size)
@@ -160,6 +164,16 @@ int qeft_attn_workspace_bytes(int n_heads, int n_split);   /* 0 for n_split == 1
 int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
                           int tab_rows, void* k_cache, void* v_cache, const int* pos, const int* out_pos, void* out,
                           void* workspace, int n_split, int n_heads, int n_kv_heads, int max_seq, qeft_stream_t stream);
+
+/* The same step on the REFERENCE's cache layout, for the `qeft_cuda.single_query_attention` boundary
+ * (qeft/kernel/qeft_cuda.cpp:23-26, ft_attention.cpp:110-181; caller ftllama_modeling.py:139-153):
+ *   k_cache_ft  fp16 [n_kv][128/8][max_seq][8]   (FasterTransformer key layout, ft_attention.cpp:131-133)
+ *   v_cache     fp16 [n_kv][max_seq][128]
+ * one sequence, head_dim 128, neox rotary from the cos/sin table (tab_rows as above), one block per head, natural output
+ * order.  The Python shim loops over the batch and raises for ALiBi / other head sizes / interleaved rotary. */
+int qeft_single_query_attention(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                                int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
+                                int n_kv_heads, int max_seq, qeft_stream_t stream);
 
 /* ---- 3-bit EXTENSION (BASELINE config 5).  The reference cannot pack or run 3 bits (QuantLinear asserts
  * bits == 4, qlinear.py:127; its quantiser can produce them, quant.py:8-10 with maxq = 7), so the layout is this

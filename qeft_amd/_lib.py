@@ -22,6 +22,7 @@ SIGNATURES = {
     "qeft_abi_version": [],
     "qeft_error_string": [_i],
     "qeft_last_hip_error": [],
+    "qeft_last_variant": [],
     "qeft_gemv_w4": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_gemv_w4_qeft": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemv_w4_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -46,6 +47,7 @@ SIGNATURES = {
     "qeft_attn_workspace_bytes": [_i, _i],
     "qeft_token_begin": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_token_end": [_p, _p, _p, _i, _i, _p],
+    "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
 }
 
@@ -68,10 +70,15 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = argtypes
-            fn.restype = (ctypes.c_char_p if name == "qeft_error_string" else
+            fn.restype = (ctypes.c_char_p if name in ("qeft_error_string", "qeft_last_variant") else
                           ctypes.c_longlong if name in ("qeft_gemm_w4_workspace_bytes", "qeft_gemm_w4_dx_workspace_bytes") else _i)
         _lib = l
     return _lib
+
+
+def last_variant():
+    """Kernel variant the calling thread's last compute entry dispatched to (qeft_last_variant)."""
+    return lib().qeft_last_variant().decode()
 
 
 def check(code):

@@ -37,6 +37,8 @@ def load_packed(model, checkpoint_path, device="cuda:0", training=False):
     ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
     if "base_path" in ckpt:
         base = ckpt["base_path"]
+        if not os.path.isabs(base) and not os.path.exists(base):     # a delta that travelled with its base file
+            base = os.path.join(os.path.dirname(os.path.abspath(checkpoint_path)), base)
         model = load_packed(model, base, device=device, training=training)
         replace_oweight(model, ckpt["oweight_state_dict"])
         return model

@@ -19,7 +19,7 @@ hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, voi
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
                                    void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
-                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st);
+                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout = false);
 size_t attn_workspace_bytes(int n_heads, int S);
 hipError_t token_begin_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
                               void* rope_row, int hidden, int vocab, int max_seq, hipStream_t st);
@@ -42,6 +42,7 @@ hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, 
 }  // namespace qeft
 
 static thread_local int g_last_hip_error = 0;
+thread_local const char* qeft::g_last_variant = "";
 // Few rows: the GEMM entry streams the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
 // Measured crossover (tools/bench_gemm.py): one 16-row slice costs ~13 us per 2^24 weights, the
 // GEMM at M <= 128 is latency-bound at ~54 us per 4096 of K whatever N is -> the GEMV route wins while
@@ -76,6 +77,8 @@ extern "C" {
 int qeft_abi_version(void) { return 1; }
 
 int qeft_last_hip_error(void) { return g_last_hip_error; }
+
+const char* qeft_last_variant(void) { return qeft::g_last_variant; }
 
 const char* qeft_error_string(int code) {
     switch (code) {
@@ -422,6 +425,18 @@ int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const voi
     if (!aligned16(k_cache) || !aligned16(v_cache) || !aligned16(workspace)) return QEFT_ERR_ALIGN;
     return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache, v_cache, pos, out_pos, out, workspace,
                                                 n_heads, n_kv_heads, max_seq, n_split, tab_rows, (hipStream_t)stream));
+}
+
+int qeft_single_query_attention(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                                int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
+                                int n_kv_heads, int max_seq, qeft_stream_t stream) {
+    if (tab_rows != 1 && tab_rows < max_seq) return QEFT_ERR_SHAPE;
+    if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || max_seq < 16 || max_seq % 16 != 0 || max_seq > 32768)
+        return QEFT_ERR_SHAPE;
+    if (!q || !k || !v || !cos_tab || !sin_tab || !k_cache_ft || !v_cache || !pos || !out) return QEFT_ERR_NULL;
+    if (!aligned16(k_cache_ft) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
+    return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache_ft, v_cache, pos, nullptr, out, nullptr,
+                                                n_heads, n_kv_heads, max_seq, 1, tab_rows, (hipStream_t)stream, true));
 }
 
 int qeft_token_begin(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h, void* rope_row,

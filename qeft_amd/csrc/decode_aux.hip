@@ -121,7 +121,15 @@ constexpr int kAttnRec = 132;   // floats per (head, split) record of the worksp
 // DH = 2 (one block per head only): the head's 128 output dims are dealt over DH blocks.  Both compute the scores (K is
 // fetched twice), each fetches half of every V row and does half of P.V; their outputs are disjoint, so there is nothing
 // to merge.  Per block 3/4 of the bytes (the bound at these sizes is what ONE CU can pull) and half of the P.V math.
-template <int PRE, int DH = 1>
+// KFT: the key cache has the reference's FasterTransformer layout [n_kv][128/8][max_seq][8] (ft_attention.cpp:131-133,
+// ftllama_modeling.py:62-65) instead of [n_kv][max_seq][128]; only the address of a 16-byte (position, 8-dim chunk)
+// piece changes -- consecutive positions of one chunk are then contiguous.
+template <bool KFT>
+__device__ __forceinline__ size_t kcache_off(int p, int chunk, int max_seq) {
+    return KFT ? ((size_t)chunk * max_seq + p) * 8 : (size_t)p * 128 + chunk * 8;
+}
+
+template <int PRE, int DH = 1, bool KFT = false>
 __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ v, const float* __restrict__ cs,
                                                                const float* __restrict__ sn, f16* __restrict__ kc,
@@ -195,9 +203,8 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
     for (int i = 0; i < PRE; ++i) {
         const int r0 = (i * NW + gw) * 16;                      // max_seq % 16 == 0: a run never straddles the cache end
         const int krow = r0 < L ? r0 + pj : 0;
-        const h8* row = (const h8*)(kch + (size_t)krow * HD + qd * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) kpre[i][j] = row[j * 4];
+        for (int j = 0; j < 4; ++j) kpre[i][j] = *(const h8*)(kch + kcache_off<KFT>(krow, qd + 4 * j, max_seq));
     }
 #pragma unroll
     for (int i = 0; i < PRE; ++i) {
@@ -223,8 +230,8 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
             knew[i] = k0;
             knew[i + 64] = k1;
             if (appender) {
-                kch[(size_t)pos * HD + i] = k0;
-                kch[(size_t)pos * HD + i + 64] = k1;
+                kch[kcache_off<KFT>(pos, i >> 3, max_seq) + (i & 7)] = k0;
+                kch[kcache_off<KFT>(pos, (i >> 3) + 8, max_seq) + (i & 7)] = k1;
             }
         }
     } else {
@@ -268,9 +275,8 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __rest
         if ((i * NW + gw) * 16 < L) score_run(i, kpre[i]);
     for (int i = PRE; (i * NW + gw) * 16 < L; ++i) {
         h8 kr[4];
-        const h8* row = (const h8*)(kch + (size_t)((i * NW + gw) * 16 + pj) * HD + qd * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) kr[j] = row[j * 4];
+        for (int j = 0; j < 4; ++j) kr[j] = *(const h8*)(kch + kcache_off<KFT>((i * NW + gw) * 16 + pj, qd + 4 * j, max_seq));
         score_run(i, kr);
     }
     const float mw = wave_max(lmax);
@@ -471,7 +477,7 @@ size_t attn_workspace_bytes(int n_heads, int S) { return S > 1 ? ((size_t)n_head
 
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
                                    void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
-                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st) {
+                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout) {
     const size_t smem = (size_t)(max_seq + 16) * 4 + 16 * 128 * 4 + 64 * 4 + 4 * 4 + 3 * 128 * 2;
     // prefetch 256 positions per head whatever the split: PRE runs of 16 on each of the 4*S waves
     int dh = 1;
@@ -487,6 +493,10 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
     };
     // measured on the 7B decode step (contexts 64..192): 682 / 689 / 688 tokens/s with 1 / 2 / 4 blocks per head
     static const int dh_env = getenv("QEFT_ATTN_DH") ? atoi(getenv("QEFT_ATTN_DH")) : 2;   // A/B switch: 1 or 2
+    if (k_ft_layout) {     // the reference's single_query_attention boundary: one block per head
+        if (S != 1) return hipErrorInvalidValue;
+        return launch(rope_attn_decode_kernel<4, 1, true>);
+    }
     if (S == 1 && dh_env == 2) {
         dh = 2;
         return launch(rope_attn_decode_kernel<4, 2>);

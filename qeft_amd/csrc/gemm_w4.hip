@@ -468,6 +468,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         if (nwv == 8) e = outl ? go(gemm_w4_kernel_v2<true, 8>) : go(gemm_w4_kernel_v2<false, 8>);
         else e = outl ? go(gemm_w4_kernel_v2<true, 4>) : go(gemm_w4_kernel_v2<false, 4>);
         if (e != hipSuccess) return e;
+        g_last_variant = nwv == 8 ? "gemm_v2_128x256" : (S > 1 ? "gemm_v2_128x128+splitk" : "gemm_v2_128x128");
         if (S > 1) {
             const size_t quads = (size_t)M * N / 4;
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, st,
@@ -476,6 +477,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         return hipGetLastError();
     }
     grid = dim3((M + BM - 1) / BM, (N + BN - 1) / BN);
+    g_last_variant = "gemm_v1";
     if (ow && n_out > 0)
         hipLaunchKernelGGL(gemm_w4_kernel<true>, grid, dim3(GEMM_THREADS), 0, st, (const f16*)x, (const uint8_t*)qw,
                            (const f16*)scales, (const f16*)zeros, (const f16*)ow, (const f16*)bias, (f16*)y, M, N, K, G,
@@ -777,6 +779,7 @@ hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales,
         hipLaunchKernelGGL(gemm_w4_dx128_kernel, grid2, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
                            (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
                            (f16*)dx, M, N, K, G, n_out);
+        g_last_variant = "dx128";
         return hipGetLastError();
     }
     int S = workspace ? gemm_w4_dx_split(M, N, K) : 1;
@@ -785,6 +788,7 @@ hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales,
     hipLaunchKernelGGL(gemm_w4_dx_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const uint8_t*)qw,
                        (const f16*)scales, (const f16*)zeros, (n_out > 0 ? (const f16*)ow : (const f16*)nullptr),
                        (f16*)dx, M, N, K, G, n_out, (float*)workspace);
+    g_last_variant = S > 1 ? "dx64+split" : "dx64";
     if (S > 1) {
         const size_t quads = (size_t)M * K / 4;
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, st,
@@ -941,8 +945,10 @@ hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, 
         dim3 grid2((N + GO_BN - 1) / GO_BN, (n_out + GO_BJ - 1) / GO_BJ);
         hipLaunchKernelGGL(grad_oweight_mfma_kernel, grid2, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (float*)dow, M,
                            N, K, n_out);
+        g_last_variant = "grad_oweight_mfma";
         return hipGetLastError();
     }
+    g_last_variant = "grad_oweight_fma";
     dim3 grid((N + 63) / 64, (n_out + 63) / 64);
     hipLaunchKernelGGL(grad_oweight_kernel, grid, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (float*)dow, M, N, K,
                        n_out);

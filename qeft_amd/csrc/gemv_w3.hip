@@ -50,6 +50,7 @@ hipError_t launch_one(const GemvArgs& a, hipStream_t st) {
     const size_t smem = gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out, rs_cap);
     if (smem > kMaxLds) return hipErrorInvalidValue;
     const dim3 grid(nblk), block(kNW * 64);
+    g_last_variant = XT == 2 ? "gemv_w3_silu" : "gemv_w3";
     if (a.n_out > 0) {
         auto kern = gemv_w4_mfma_kernel<kNW, 1, D, true, false, XT, 0, 3>;
         if (hipError_t e = raise_lds(kern, smem)) return e;
@@ -67,6 +68,7 @@ hipError_t launch_rows(const GemvArgs& a, hipStream_t st) {
     const size_t smem = gemv_mfma_smem_bytes(kNW, a.m_rt, a.K, a.n_out);
     if (smem > kMaxLds) return hipErrorInvalidValue;
     const dim3 grid(a.N / 16), block(kNW * 64);
+    g_last_variant = "gemv_w3_rows";
     if (a.n_out > 0) {
         auto kern = gemv_w4_mfma_kernel<kNW, 16, 4, true, false, 0, 0, 3>;
         if (hipError_t e = raise_lds(kern, smem)) return e;
@@ -112,6 +114,7 @@ template <int D>
 static hipError_t launch_group3(const GemvGroupArgs& g, int nblocks, int rs_cap, hipStream_t st) {
     const size_t smem = gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out, rs_cap);
     const dim3 grid(nblocks), block(kNW * 64);
+    g_last_variant = "gemv_w3_group";
     if (g.xt_aux) {
         if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 1, 3>), grid, block, smem, st, g, rs_cap);
         else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 1, 3>), grid, block, smem, st, g, rs_cap);

@@ -34,6 +34,7 @@ static hipError_t launch(const GemvArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
     }
+    g_last_variant = "gemv_valu";
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kNW * 64), smem, st, a);
     return hipGetLastError();
 }
@@ -105,6 +106,7 @@ static hipError_t launch_mfma(const GemvArgs& a, hipStream_t st) {
     if (xg) { if (outl) QEFT_LAUNCH(true, true); else QEFT_LAUNCH(false, true); }
     else { if (outl) QEFT_LAUNCH(true, false); else QEFT_LAUNCH(false, false); }
 #undef QEFT_LAUNCH
+    g_last_variant = "gemv_mfma";
     return hipGetLastError();
 }
 
@@ -160,6 +162,7 @@ hipError_t gemv_w4_smallm_dispatch(const GemvArgs& a0, int m, hipStream_t st) {
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
+    g_last_variant = "gemv_smallm";
     return hipSuccess;
 }
 
@@ -218,6 +221,7 @@ template <int RGI, int D>
 static hipError_t launch_group(const GemvGroupArgs& g, int nblocks, hipStream_t st) {
     const size_t smem = gemv_smem_bytes(kNW, RGI, 1, g.K, g.G, g.n_out);
     const dim3 grid(nblocks), block(kNW * 64);
+    g_last_variant = "gemv_valu_group";
     if (g.xt_aux) {
         if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, true, 1>), grid, block, smem, st, g);
         else hipLaunchKernelGGL((gemv_w4_group_kernel<kNW, RGI, 1, D, false, 1>), grid, block, smem, st, g);
@@ -232,6 +236,7 @@ template <int D>
 static hipError_t launch_mfma_group(const GemvGroupArgs& g, int nblocks, int rs_cap, hipStream_t st) {
     const size_t smem = gemv_mfma_smem_bytes(kNW, 1, g.K, g.n_out, rs_cap);
     const dim3 grid(nblocks), block(kNW * 64);
+    g_last_variant = "gemv_mfma_group";
     if (g.xt_aux) {
         if (g.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, true, 1>), grid, block, smem, st, g, rs_cap);
         else hipLaunchKernelGGL((gemv_w4_mfma_group_kernel<kNW, D, false, 1>), grid, block, smem, st, g, rs_cap);
@@ -306,6 +311,7 @@ template <int RGI, int D>
 static hipError_t launch_silu(const GemvArgs& a, hipStream_t st) {
     const size_t smem = gemv_smem_bytes(kNW, RGI, 1, a.K, a.G, a.n_out);
     const dim3 grid(a.N / (4 * RGI)), block(kNW * 64);
+    g_last_variant = "gemv_valu_silu";
     if (a.n_out > 0) hipLaunchKernelGGL((gemv_w4_kernel<kNW, RGI, 1, D, true, false, 0, 2>), grid, block, smem, st, a);
     else hipLaunchKernelGGL((gemv_w4_kernel<kNW, RGI, 1, D, false, false, 0, 2>), grid, block, smem, st, a);
     return hipGetLastError();
@@ -318,6 +324,7 @@ static hipError_t launch_mfma_silu(const GemvArgs& a, hipStream_t st) {
     if (gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out, rs_cap) > 64 * 1024) { nblk = nsets; rs_cap = 1; }
     const size_t smem = gemv_mfma_smem_bytes(kNW, 1, a.K, a.n_out, rs_cap);
     const dim3 grid(nblk), block(kNW * 64);
+    g_last_variant = "gemv_mfma_silu";
     if (a.n_out > 0) hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, true, false, 2, 0>), grid, block, smem, st, a, rs_cap);
     else hipLaunchKernelGGL((gemv_w4_mfma_kernel<kNW, 1, D, false, false, 2, 0>), grid, block, smem, st, a, rs_cap);
     return hipGetLastError();

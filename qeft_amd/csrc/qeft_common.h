@@ -87,6 +87,10 @@ struct GemvGroupArgs {
     const uint32_t* sz_blk[3];
 };
 
+// Name of the kernel variant the calling thread's most recent entry point dispatched to (qeft_last_variant(), capi.hip).
+// Tests assert it so that coverage cannot silently fall off a routing threshold.
+extern thread_local const char* g_last_variant;
+
 __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 
 // silu(g) = g / (1 + e^-g) in fp32 with the hardware reciprocal (1 ulp) instead of an IEEE division: the result is

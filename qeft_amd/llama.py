@@ -386,6 +386,8 @@ class DecodeEngine:
 
     def set_position(self, t):
         """The next token to be fed sits at position t (the KV caches hold positions < t)."""
+        if not 0 <= int(t) <= self.m.shape.max_seq:
+            raise ValueError(f"position {t} outside the KV cache (max_seq = {self.m.shape.max_seq})")
         self.pos.fill_(t)
         self.host_pos = int(t)
 
@@ -526,7 +528,8 @@ class DecodeEngine:
         self.tok.copy_(tok0)
         if linears_only:
             return graph
-        self.graph = self.graphs[self.attn_split] = graph
+        # a graph bakes in the attention split AND whether token_end writes the greedy token
+        self.graph = self.graphs[(self.attn_split, bool(self.greedy))] = graph
         return graph
 
     def precapture(self, max_pos):
@@ -534,14 +537,17 @@ class DecodeEngine:
         captured inside a timed region)."""
         for sp in sorted({self._split_for(p) for p in (self.host_pos, 255, 256, 1535, 1536, max_pos - 1)
                           if self.host_pos <= p < max_pos}):
-            if sp not in self.graphs:
+            if (sp, bool(self.greedy)) not in self.graphs:
                 self.capture(split=sp)
 
     def step(self):
         """Run one token: consumes self.tok at position self.pos, leaves logits (and, if greedy, the next token)."""
+        if self.host_pos >= self.m.shape.max_seq:
+            # the device side would skip the attention (stale output) and keep counting: refuse instead
+            raise RuntimeError(f"KV cache full: position {self.host_pos} >= max_seq {self.m.shape.max_seq}")
         sp = self._split_for(self.host_pos)
         if self.use_graph:
-            g = self.graphs.get(sp)
+            g = self.graphs.get((sp, bool(self.greedy)))
             if g is None:
                 g = self.capture(split=sp)
             g.replay()

@@ -248,3 +248,79 @@ def expand_3bit(qweight3, n, k, n_out, out=None):
     with torch.cuda.device(qweight3.device):
         _lib.check(_lib.lib().qeft_expand_w3(qweight3.data_ptr(), out.data_ptr(), n, k, n_out, _stream(qweight3)))
     return out
+
+
+# ---- the two FasterTransformer-derived entries of the reference module (qeft_cuda.cpp:22-26), imported unconditionally
+# ---- by qeft/monkeypatch/ftllama_modeling.py:18.  Not on the packed-weight path; adapters over the decode helpers.
+def layernorm_forward_cuda(x, gamma, out, eps):
+    """RMSNorm `out = x * rsqrt(mean(x^2) + eps) * gamma` (qeft/kernel/layernorm/layernorm.cu:94-110: input [b, n, c],
+    m = b*n rows of c; T5 layer norm = no mean subtraction, no beta).  Writes into `out`, returns None like the reference."""
+    _need(x.is_cuda and x.dtype == torch.float16 and gamma.dtype == torch.float16 and out.dtype == torch.float16,
+          "expected Half GPU tensors")
+    _need(x.dim() == 3, "input must be [b, n, c]")
+    _need(x.is_contiguous() and out.is_contiguous() and gamma.is_contiguous(), "tensors must be contiguous")
+    _need(out.shape == x.shape and gamma.numel() == x.shape[2], "shape mismatch")
+    m, c = x.shape[0] * x.shape[1], x.shape[2]
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().qeft_rmsnorm(x.data_ptr(), None, gamma.data_ptr(), None, out.data_ptr(), m, c, float(eps),
+                                           _stream(x)))
+
+
+_ROPE_TABLES = {}   # (device, rotary_dim, base, rows) -> fp32 [2][rows][64]: cos table, sin table
+
+
+def _rope_table(device, dim, base, rows):
+    key = (device, dim, float(base), rows)
+    tab = _ROPE_TABLES.get(key)
+    if tab is None:
+        half = 64
+        if dim == 0:       # no rotary: identity rotation
+            tab = torch.stack([torch.ones(rows, half), torch.zeros(rows, half)])
+        else:
+            inv = 1.0 / (float(base) ** (torch.arange(0, half, dtype=torch.float64) / half))
+            ang = torch.arange(rows, dtype=torch.float64)[:, None] * inv[None, :]
+            tab = torch.stack([ang.cos(), ang.sin()])
+        tab = _ROPE_TABLES[key] = tab.float().contiguous().to(device)
+    return tab
+
+
+def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_slopes_, timestep,
+                           rotary_embedding_dim=0, rotary_base=10000.0, neox_rotary_style=True):
+    """ft_attention.cpp:110-181 with the reference's positional signature and cache layouts:
+        q [B, H, 128], k / v [B, Hkv, 128] fp16 (last-dim stride 1, head stride 128)
+        k_cache [B, Hkv, 128/8, L, 8], v_cache [B, Hkv, L, 128] fp16 contiguous
+    Rotates q / k at position `timestep` (neox style, rotary_embedding_dim in {0, 128}), appends k / v to the caches at
+    that position and returns softmax(q K^T / sqrt(128)) V as a new tensor shaped like q.  length_per_sample_ (int32 [B],
+    optional): per-sample position instead of `timestep` (ft_attention.cpp:143-149).
+    Not supported (RuntimeError): ALiBi slopes, head sizes other than 128, interleaved (GPT-J) rotary, fp32 / bf16."""
+    _need(q.is_cuda and q.dtype == torch.float16, "single_query_attention: only Half GPU tensors are supported")
+    _need(alibi_slopes_ is None, "single_query_attention: ALiBi is not supported by the MI355X build")
+    _need(neox_rotary_style, "single_query_attention: only neox-style (non-interleaved) rotary is supported")
+    B, Hkv, L, D = v_cache.shape
+    H = q.shape[1]
+    _need(D == 128, "single_query_attention: head_dim must be 128")
+    _need(rotary_embedding_dim in (0, D), "single_query_attention: rotary_embedding_dim must be 0 or head_dim")
+    _need(tuple(q.shape) == (B, H, D) and tuple(k.shape) == (B, Hkv, D) and tuple(v.shape) == (B, Hkv, D), "bad q/k/v shape")
+    _need(tuple(k_cache.shape) == (B, Hkv, D // 8, L, 8), "k_cache must be [B, Hkv, Dh/8, L, 8]")
+    _need(k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == torch.float16
+          and v_cache.dtype == torch.float16, "caches must be contiguous Half tensors")
+    for t in (q, k, v):
+        _need(t.stride(2) == 1 and t.stride(1) == D, "q/k/v: last-dim stride 1 and head stride head_dim")
+    _need(L % 16 == 0 and 16 <= L <= 32768, "cache length must be a multiple of 16 in [16, 32768]")
+    _need(H % Hkv == 0, "n_heads must be a multiple of n_kv_heads")
+    if length_per_sample_ is not None:
+        _need(length_per_sample_.dtype == torch.int32 and length_per_sample_.is_cuda and length_per_sample_.numel() == B
+              and length_per_sample_.is_contiguous(), "length_per_sample_ must be a contiguous int32 [B] GPU tensor")
+        pos = length_per_sample_
+    else:
+        _need(0 <= int(timestep) < L, f"timestep {timestep} outside the cache (length {L})")
+        pos = torch.full((B,), int(timestep), dtype=torch.int32, device=q.device)
+    tab = _rope_table(q.device, rotary_embedding_dim, rotary_base, L)
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        lib, st = _lib.lib(), _stream(q)
+        for b in range(B):      # the kernel serves one sequence per launch (decode harness); the batch is a host loop
+            _lib.check(lib.qeft_single_query_attention(
+                q[b].data_ptr(), k[b].data_ptr(), v[b].data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), L,
+                k_cache[b].data_ptr(), v_cache[b].data_ptr(), pos.data_ptr() + 4 * b, out[b].data_ptr(), H, Hkv, L, st))
+    return out

@@ -233,10 +233,13 @@ class QuantLinear(nn.Module):
         self.sz_packed = qeft_cuda.pack_scales(self.scales, self.scaled_zeros, self.outfeatures, self.infeatures,
                                                self.group_size)
         if self.outlierfeatures > 0:
-            if self.oweight.shape[1] % 64 > 0:  # same left-padding as the reference (:221-222)
-                pad = 64 - self.oweight.shape[1] % 64
-                self.oweight = torch.cat([torch.zeros((self.oweight.shape[0], pad), dtype=self.oweight.dtype,
-                                                      device=self.oweight.device), self.oweight], dim=-1)
+            # The reference left-pads oweight to a multiple of 64 columns here (qlinear.py:221-222) for its cuBLAS
+            # F.linear and thereby breaks its own GEMM path for r % 64 != 0 (shape error).  No kernel of this build
+            # consumes a padded slice -- the fused GEMM / dX / d(oweight) kernels take r = oweight.shape[1] as the
+            # number of fp16 columns -- so oweight keeps its [N, r] shape (a padded one would silently turn live INT4
+            # columns into zero-weight outlier columns in the training path).
+            if self.oweight.shape[1] != self.outlierfeatures:     # a checkpoint saved after the reference's set_kernel
+                self.oweight = self.oweight[:, -self.outlierfeatures:].contiguous()
             self.gemv = qeft_cuda.gemv_4bit_qeft
             self.gemm = qeft_cuda.gemm_4bit
             self.forward = self.forward_outlier

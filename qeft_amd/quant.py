@@ -16,25 +16,33 @@ def quantize(x, scale, zero, minq, maxq):
     return scale * (q - zero)
 
 
-def minmax_params(w, group_size, bits=4):
-    """Per-group asymmetric min-max (scale, zero), fp32 [N, K/g]  (reference quant.py:142-158, sym=False)."""
+def minmax_params(w, group_size, bits=4, sym=False):
+    """Per-group min-max (scale, zero), fp32 [N, K/g]  (reference quant.py:142-158; sym=True: the symmetric branch,
+    grid -2^(b-1)..2^(b-1)-1, zero = 0 -- QuantLinear.pack(sym=True) then shifts the zeros by 2^(b-1))."""
     n, k = w.shape
-    maxq = 2 ** bits - 1
     g = w.float().reshape(n, k // group_size, group_size)
     xmin = torch.minimum(g.amin(-1), torch.zeros((), device=w.device))
     xmax = torch.maximum(g.amax(-1), torch.zeros((), device=w.device))
+    if sym:
+        xmax = torch.maximum(xmin.abs(), xmax)
+        xmin = torch.where(xmin < 0, -xmax, xmin)
     dead = (xmin == 0) & (xmax == 0)
     xmin = torch.where(dead, -torch.ones_like(xmin), xmin)
     xmax = torch.where(dead, torch.ones_like(xmax), xmax)
+    if sym:
+        scale = xmax / ((2 ** bits - 1) // 2 + 1)
+        return scale, torch.zeros_like(scale)
+    maxq = 2 ** bits - 1
     scale = (xmax - xmin) / maxq
     zero = torch.round(-xmin / scale)
     return scale, zero
 
 
-def fake_quantize(w, scale, zero, group_size, bits=4):
+def fake_quantize(w, scale, zero, group_size, bits=4, sym=False):
     s = torch.repeat_interleave(scale, group_size, dim=1)
     z = torch.repeat_interleave(zero, group_size, dim=1)
-    return quantize(w.float(), s, z, 0, 2 ** bits - 1)
+    minq, maxq = (-((2 ** bits - 1) // 2 + 1), (2 ** bits - 1) // 2) if sym else (0, 2 ** bits - 1)
+    return quantize(w.float(), s, z, minq, maxq)
 
 
 def find_layers(module, layers=(nn.Linear,), name=""):

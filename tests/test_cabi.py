@@ -94,3 +94,26 @@ def test_binding_puts_torch_hip_runtime_first():
     code = "import sys; from qeft_amd import _lib; assert 'torch' in sys.modules; print('ok')"
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_shim_exports_the_reference_module_surface():
+    """Every function the reference binds in qeft_cuda.cpp:10-27 exists in the module a reference caller imports, with
+    the reference's positional parameters (the two FT entries keep their pybind defaults, qeft_cuda.cpp:23-26)."""
+    import inspect
+    import qeft_cuda
+    want = {
+        "gemm_4bit": ["in_feats", "kernel", "scales", "zeros"],
+        "gemv_4bit": ["in_feats", "kernel", "scaling_factors", "zeros", "m", "n", "k", "group_size"],
+        "gemv_4bit_qeft": ["in_feats", "kernel", "scaling_factors", "zeros", "oweight", "m", "n", "k", "group_size"],
+        "layernorm_forward_cuda": ["x", "gamma", "out", "eps"],
+        "single_query_attention": ["q", "k", "v", "k_cache", "v_cache", "length_per_sample_", "alibi_slopes_", "timestep",
+                                   "rotary_embedding_dim", "rotary_base", "neox_rotary_style"],
+    }
+    for name, params in want.items():
+        sig = inspect.signature(getattr(qeft_cuda, name))
+        assert list(sig.parameters) == params, name
+    d = inspect.signature(qeft_cuda.single_query_attention).parameters
+    assert d["rotary_embedding_dim"].default == 0 and d["rotary_base"].default == 10000.0 and d["neox_rotary_style"].default is True
+    x = torch.zeros(1, 2, 128, dtype=torch.float16)
+    with pytest.raises(RuntimeError):        # CPU tensors raise: no host fallback for the FT entries either
+        qeft_cuda.layernorm_forward_cuda(x, torch.ones(128, dtype=torch.float16), torch.empty_like(x), 1e-5)

@@ -1,0 +1,114 @@
+"""GPU parity at the sizes BASELINE.json's configs run at -- the kernels a prefill (M = 2048), a fine-tune step
+(M = 2048 backward) and a row-sharded 13B decode actually dispatch to.  Every case asserts the variant the launch took
+(qeft_last_variant), so coverage cannot fall off a routing threshold unnoticed.  Oracle time is kept small by checking a
+sample of output columns (first / last / random), never by shrinking the launch."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qeft_oracle as O
+from util import REL_TOL, layer_to_torch, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+R, G, M = 128, 128, 2048
+SHAPES = [(4096, 4096), (11008, 4096), (4096, 11008)]
+
+
+@functools.lru_cache(maxsize=2)
+def _layer(n, k):
+    bufs = O.make_layer(n, k, R, G, seed=n // 7 + k)
+    w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], G)   # fp32 [N, K]
+    return bufs, w
+
+
+def _sample(n, count=256, seed=0):
+    return np.unique(np.concatenate([np.arange(0, 64), np.arange(n - 64, n),
+                                     np.random.default_rng(seed).integers(0, n, count)]))
+
+
+@pytest.mark.parametrize("n,k", SHAPES)
+def test_gemm_forward_m2048(n, k):
+    """BASELINE config 3 (prefill seq = 2048): the tier the reference calls T2 (gemm_cuda.cu:1005-1029)."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs, w = _layer(n, k)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(M, k, R, seed=5)
+    bias = (np.random.default_rng(1).standard_normal(n) * 0.1).astype(np.float16)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"],
+                                 torch.from_numpy(bias).to(DEV))
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant in ("gemm_v3_256x128", "gemm_v2_128x256"), variant       # the M >= 2048 tiers, never the 128x128 tile
+    rows = _sample(n)
+    yref = x.astype(np.float64) @ w[rows].astype(np.float64).T + bias[rows].astype(np.float64)
+    y = y.cpu().numpy()
+    assert y.shape == (M, n)
+    assert rel_err(y[:, rows], yref) < REL_TOL
+    # every M tile and every N tile carries data: no all-zero 128 x 128 block anywhere in the output
+    blocks = np.abs(y.astype(np.float32)).reshape(M // 128, 128, n // 128, 128).max(axis=(1, 3))
+    assert (blocks > 0).all()
+
+
+@pytest.mark.parametrize("n,k", SHAPES)
+def test_gemm_dx_and_grad_oweight_m2048(n, k):
+    """BASELINE config 5: the backward of one fine-tune step at M = 2048 (QuantMatMulQEFT.backward, qlinear.py:30-44)."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs, w = _layer(n, k)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(M, k, R, seed=6)
+    dy = (np.random.default_rng(7).standard_normal((M, n)) * 0.1).astype(np.float16)
+    dyt, xt = torch.from_numpy(dy).to(DEV), torch.from_numpy(x).to(DEV)
+    dx = qeft_cuda.gemm_4bit_dx(dyt, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
+    v_dx = _lib.last_variant()
+    dow = qeft_cuda.grad_oweight(dyt, xt, R)
+    v_dow = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert v_dx in ("dx256", "dx128"), v_dx
+    assert v_dow == "grad_oweight_mfma", v_dow
+    cols = np.unique(np.concatenate([_sample(k - R), np.arange(k - R, k)]))      # sample of INT4 columns + the whole fp16 slice
+    dx_ref = dy.astype(np.float64) @ w[:, cols].astype(np.float64)
+    dx = dx.cpu().numpy()
+    assert dx.shape == (M, k)
+    assert rel_err(dx[:, cols], dx_ref) < REL_TOL
+    dow_ref = dy.astype(np.float64).T @ x[:, k - R:].astype(np.float64)
+    assert rel_err(dow.cpu().numpy(), dow_ref) < REL_TOL
+
+
+@pytest.mark.parametrize("n,k", [(640, 5120), (1728, 5120), (640, 13824), (2560, 5120), (6912, 5120), (1376, 4096), (512, 11008)])
+@pytest.mark.parametrize("m", [1, 3])
+def test_gemv_row_shard_shapes(n, k, m):
+    """BASELINE config 4: the per-rank row shards of Llama-2-13B at 8 and 2 GPUs (and of 7B at 8)."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, R, G, seed=n + k + m)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, R, seed=m)
+    y = qeft_cuda.gemv_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                 t["oweight_interleaved"], m, n, k, G)
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant in ("gemv_mfma", "gemv_v3"), variant
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], None, G)
+    assert rel_err(y.cpu().numpy(), yref.astype(np.float64)) < REL_TOL
+
+
+def test_variant_names_follow_the_routing():
+    """The routing tiers below the BASELINE sizes keep their own names (and their own tests in test_gpu_gemm.py)."""
+    from qeft_amd import _lib, qeft_cuda
+    n, k = 512, 1024
+    bufs = O.make_layer(n, k, R, G, seed=3)
+    t = layer_to_torch(bufs, DEV)
+    seen = {}
+    for m in (8, 200, 1024):
+        x = torch.from_numpy(O.make_activation(m, k, R, seed=m)).to(DEV)
+        qeft_cuda.gemm_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
+        seen[m] = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert seen[8] == "gemv_smallm", seen
+    assert seen[200].startswith("gemm_v2_128x128"), seen
+    dy = torch.zeros(64, n, dtype=torch.float16, device=DEV)
+    qeft_cuda.gemm_4bit_dx(dy, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
+    assert _lib.last_variant().startswith("dx64")
+    torch.cuda.synchronize()

@@ -342,10 +342,113 @@ def test_attention_split_follows_the_position():
     eng = DecodeEngine(model, use_graph=True)
     assert [eng._split_for(p) for p in (0, 255, 256, 1535, 1536)] == [1, 1, 4, 4, 8]
     got = eng.teacher_forced_logits(tokens)
-    assert sorted(eng.graphs) == [1, 4] and eng.host_pos == 300
+    assert sorted(eng.graphs) == [(1, False), (4, False)] and eng.host_pos == 300
     one = DecodeEngine(model, use_graph=False)
     one.attn_split_forced = 1
     ref = one.teacher_forced_logits(tokens)
     torch.cuda.synchronize()
     assert torch.equal(got[:256], ref[:256])                       # same kernels, same order before the switch
     assert (got - ref).abs().max().item() / ref.abs().max().item() < 5e-3
+
+
+def test_engine_refuses_to_run_past_the_kv_cache():
+    """host-side guard: at position max_seq the device side would skip the attention and keep counting (stale output)."""
+    from qeft_amd.llama import DecodeEngine, QuantLlama, tiny_shape
+    shape = tiny_shape(n_layers=1, hidden=256, inter=512, n_heads=2, vocab=128, max_seq=32)
+    eng = DecodeEngine(QuantLlama(shape, DEV, seed=3), use_graph=False)
+    eng.set_position(31)
+    eng.step()
+    with pytest.raises(RuntimeError, match="KV cache full"):
+        eng.step()
+    with pytest.raises(ValueError):
+        eng.set_position(33)
+
+
+def test_graphs_are_keyed_by_split_and_greedy():
+    """A graph captured with greedy token_end must not be replayed for a teacher-forced run (and vice versa)."""
+    from qeft_amd.llama import DecodeEngine, QuantLlama, tiny_shape
+    shape = tiny_shape(n_layers=1, hidden=256, inter=512, n_heads=2, vocab=128, max_seq=32)
+    eng = DecodeEngine(QuantLlama(shape, DEV, seed=4), use_graph=True)
+    eng.greedy = True
+    eng.tok.fill_(3)
+    eng.step()
+    first = int(eng.tok.item())
+    eng.reset()
+    eng.greedy = False
+    eng.tok.fill_(3)
+    eng.step()
+    torch.cuda.synchronize()
+    assert int(eng.tok.item()) == 3                      # the non-greedy graph leaves the fed token alone
+    assert sorted(eng.graphs) == [(1, False), (1, True)]
+    assert first == int(eng.logits[0].float().argmax().item())
+
+
+# ---- the reference module's FasterTransformer-derived entries (qeft_cuda.cpp:22-26) through the `qeft_cuda` shim -------
+def test_shim_layernorm_forward_cuda():
+    import qeft_cuda                                            # the top-level alias a reference caller imports
+    torch.manual_seed(0)
+    x = (torch.randn(2, 5, 512, device=DEV) * 3).half()
+    gamma = (1 + 0.1 * torch.randn(512, device=DEV)).half()
+    out = torch.empty_like(x)
+    assert qeft_cuda.layernorm_forward_cuda(x, gamma, out, 1e-5) is None       # positional, writes `out` (layernorm.cu:94-110)
+    torch.cuda.synchronize()
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma.float()
+    assert (out.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    with pytest.raises(RuntimeError):
+        qeft_cuda.layernorm_forward_cuda(x.float(), gamma, out, 1e-5)
+
+
+@pytest.mark.parametrize("B,H,Hkv,rot", [(1, 4, 4, 128), (2, 8, 2, 128), (1, 2, 2, 0)])
+def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot):
+    """Positional call exactly as ftllama_modeling.py:139-153 makes it, caches in the reference's layouts
+    (k_cache [B, Hkv, Dh/8, L, 8], v_cache [B, Hkv, L, Dh]); checked against a plain fp32 PyTorch decode."""
+    import math
+    import qeft_cuda
+    D, L, T = 128, 64, 21
+    torch.manual_seed(B * 10 + H)
+    k_cache = torch.zeros(B, Hkv, D // 8, L, 8, dtype=torch.float16, device=DEV)
+    v_cache = torch.zeros(B, Hkv, L, D, dtype=torch.float16, device=DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, dtype=torch.float64) / 64))
+
+    def rope(x, p):       # [.., 128] fp32, neox style
+        if rot == 0:
+            return x
+        ang = (p * inv).float().to(x.device)
+        c, s = ang.cos(), ang.sin()
+        a, b = x[..., :64], x[..., 64:]
+        return torch.cat([a * c - b * s, b * c + a * s], -1)
+
+    ks, vs = [], []
+    for t in range(T):
+        q = torch.randn(B, H, D, device=DEV).half()
+        k = torch.randn(B, Hkv, D, device=DEV).half()
+        v = torch.randn(B, Hkv, D, device=DEV).half()
+        out = qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, t, rot, 10000.0, True)
+        torch.cuda.synchronize()
+        assert out.shape == q.shape and out.dtype == torch.float16
+        ks.append(rope(k.float(), t).half().float())
+        vs.append(v.float())
+        K, V = torch.stack(ks, 2), torch.stack(vs, 2)                          # [B, Hkv, t+1, D]
+        K, V = K.repeat_interleave(H // Hkv, 1), V.repeat_interleave(H // Hkv, 1)
+        att = torch.einsum("bhd,bhtd->bht", rope(q.float(), t), K) / math.sqrt(D)
+        ref = torch.einsum("bht,bhtd->bhd", att.softmax(-1), V)
+        assert (out.float() - ref).abs().max().item() < 2e-2 * max(ref.abs().max().item(), 1.0), t
+    # the caches hold what the reference's would: rotated keys in the FT layout, values as they came
+    Kc = k_cache.permute(0, 1, 3, 2, 4).reshape(B, Hkv, L, D)[:, :, :T].float()
+    assert (Kc - torch.stack(ks, 2)).abs().max().item() < 2e-3 * 4
+    assert torch.equal(v_cache[:, :, :T].float(), torch.stack(vs, 2))
+    assert float(k_cache.permute(0, 1, 3, 2, 4).reshape(B, Hkv, L, D)[:, :, T:].abs().max()) == 0.0
+    # unsupported arguments raise (documented in the shim)
+    with pytest.raises(RuntimeError, match="ALiBi"):
+        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, torch.zeros(H, device=DEV), T, rot, 10000.0, True)
+    with pytest.raises(RuntimeError, match="neox"):
+        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, T, rot, 10000.0, False)
+    with pytest.raises(RuntimeError, match="timestep"):
+        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, L, rot, 10000.0, True)
+    # per-sample lengths instead of the common timestep (ft_attention.cpp:143-149)
+    lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
+    o1 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), lens, None, 0, rot, 10000.0, True)
+    o2 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), None, None, T, rot, 10000.0, True)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)

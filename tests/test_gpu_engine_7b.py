@@ -1,0 +1,62 @@
+"""Whole-model parity at the BASELINE shape (config 2: "Llama-2-7B w4 g128 r128 ... PPL vs reference"): the 7B-shape
+decode engine the bench times, teacher-forced, against the plain fp32 PyTorch model over the dense dequantised weights.
+SURVEY.md section 8(d): |dNLL| <= 1e-3 on the same random tokens."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NLL_TOL = 1e-3
+LOGIT_TOL = 2e-2    # max |dlogit| / max |logit|: fp16 residual stream over 32 layers vs fp32
+
+
+@pytest.fixture(scope="module")
+def model7b():
+    import dataclasses
+    from qeft_amd.llama import LLAMA2_7B, QuantLlama
+    shape = dataclasses.replace(LLAMA2_7B, max_seq=512)
+    model = QuantLlama(shape, DEV, seed=0, fast_init=True)
+    dense = model.dense_weights()          # fp32, ~26 GB: fine on a 288 GB part
+    yield model, dense
+    del dense, model
+    torch.cuda.empty_cache()
+
+
+def _compare(got, ref, tokens):
+    from qeft_amd.llama import nll_from_logits
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item() / scale
+    dn = abs(nll_from_logits(got, tokens) - nll_from_logits(ref, tokens))
+    assert err < LOGIT_TOL, err
+    assert dn <= NLL_TOL, dn
+    # the argmax sequence agrees wherever the dense model's top-2 margin exceeds the logit tolerance
+    top2 = ref.topk(2, dim=-1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL * scale
+    assert torch.equal(got.argmax(-1)[sure], ref.argmax(-1)[sure])
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_engine_7b_first_tokens(model7b, use_graph):
+    """24 tokens from position 0 (one attention block per head throughout): hipGraph replay and eager launches."""
+    from qeft_amd.llama import DecodeEngine
+    model, dense = model7b
+    eng = DecodeEngine(model, use_graph=use_graph)
+    tokens = torch.randint(0, model.shape.vocab, (24,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    got = eng.teacher_forced_logits(tokens)
+    ref = model.forward_dense_reference(tokens, dense)
+    torch.cuda.synchronize()
+    _compare(got, ref, tokens)
+
+
+def test_engine_7b_crosses_position_256(model7b):
+    """272 tokens: the engine switches from the 1-block-per-head graph to the 4-block one at position 256."""
+    from qeft_amd.llama import DecodeEngine
+    model, dense = model7b
+    eng = DecodeEngine(model, use_graph=True)
+    tokens = torch.randint(0, model.shape.vocab, (272,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    got = eng.teacher_forced_logits(tokens)
+    assert {sp for sp, _ in eng.graphs} >= {1, 4}       # both splits were captured and replayed
+    ref = model.forward_dense_reference(tokens, dense)
+    torch.cuda.synchronize()
+    _compare(got, ref, tokens)
+    _compare(got[250:], ref[250:], tokens[250:])       # the positions around and past the switch on their own

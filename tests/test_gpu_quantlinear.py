@@ -89,6 +89,39 @@ def test_training_autograd_matches_dense_linear_autograd():
     assert ql.qweight.grad is None
 
 
+@pytest.mark.parametrize("r,name", [(32, "model.layers.0.mlp.up_proj"), (96, "model.layers.0.self_attn.o_proj")])
+def test_training_with_outlier_counts_that_are_not_multiples_of_64(r, name):
+    """r % 64 != 0: the reference pads oweight in set_kernel and then fails with a shape error in its GEMM path; here
+    oweight keeps its [N, r] shape and forward / dX / d(oweight) are those of the dense layer."""
+    n, k, g, m = 256, 1024, 128, 40
+    ql, bufs, oidx = build(n, k, r, g, name, seed=11)
+    ql.set_kernel(training=True)
+    ql.set_for_wct()
+    assert tuple(ql.oweight.shape) == (n, r)
+    x = torch.from_numpy(O.make_activation(m, k, r, seed=2)).to(DEV).requires_grad_(True)
+    y = ql(x)
+    gy = (torch.randn(m, n, generator=torch.Generator().manual_seed(3)) * 0.1).half().to(DEV)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    w = torch.from_numpy(O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], g)).to(DEV)
+    xr = x.detach().float().requires_grad_(True)
+    ow = w[:, k - r:].clone().requires_grad_(True)
+    xin = xr[:, torch.from_numpy(O.sparse_to_dense_ids(oidx, k)).to(DEV)] if "o_proj" in name else xr
+    yr = xin @ torch.cat([w[:, :k - r], ow], 1).T
+    yr.backward(gy.float())
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < REL_TOL
+    assert rel_err(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < REL_TOL
+    assert tuple(ql.oweight.grad.shape) == (n, r)
+    assert rel_err(ql.oweight.grad.cpu().numpy(), ow.grad.cpu().numpy()) < REL_TOL
+    ql.set_kernel(training=False)            # and back to inference: decode + prefill paths on the same module
+    for mm in (2, 24):
+        xi = torch.from_numpy(O.make_activation(mm, k, r, seed=mm)).to(DEV)
+        ids = O.sparse_to_dense_ids(oidx, k) if "o_proj" in name else None
+        yref = O.quant_linear(xi.cpu().numpy(), bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"],
+                              None, g, reorder_ids=ids)
+        assert rel_err(ql(xi).detach().cpu().numpy(), yref.astype(np.float64)) < REL_TOL
+
+
 def test_checkpoint_roundtrip_and_finetuned_delta(tmp_path):
     from argparse import Namespace
     from qeft_amd import checkpoint
@@ -127,9 +160,8 @@ def test_checkpoint_roundtrip_and_finetuned_delta(tmp_path):
     for name in q1:
         for key, val in q1[name].state_dict().items():
             got = q2[name].state_dict()[key].cpu()
-            if key == "oweight":   # set_kernel() left-pads oweight to a multiple of 64 columns (qlinear.py:221-222)
-                assert got.shape[1] % 64 == 0 and torch.all(got[:, :got.shape[1] - val.shape[1]] == 0)
-                got = got[:, -val.shape[1]:]
+            if key == "oweight":   # unlike the reference (qlinear.py:221-222) set_kernel() does not pad oweight
+                assert got.shape == val.shape
             assert torch.equal(val, got), (name, key)
     y0 = m2.up_proj(x.to(DEV))
     # fine-tuned delta: only oweight travels, and the interleaved copy is refreshed on load

@@ -1,0 +1,83 @@
+"""Guard for the fault class of the two round-1 development aborts: UNCONDITIONAL prefetch / staging
+loads whose address was not clamped into the operand -- a wave without ring steps re-reading "step 0" of a row group
+shorter than one wave-wide load (K < one step), and a ring prefetch running past a wave's last step.  Such reads are
+never consumed, so no numeric check sees them; they fault only when the operand ends where its mapping ends.
+
+The cases below run in a child process with PYTORCH_NO_CUDA_MEMORY_CACHING=1 (every tensor its own hipMalloc, so an
+operand ends at the end of its allocation instead of somewhere inside a 2 MiB pool segment), on the shapes where the
+clamps bite: one 16-row set, K below / at / just above one step and one staging pass, last blocks with fewer row sets
+than rs_cap, batch slices, ragged GEMM tiles.  Every result is also checked against the oracle, so a clamp that
+"fixes" a fault by reading the wrong bytes fails too.  Runs last (file name) and once."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np, torch
+from oracle import qeft_oracle as O
+from util import layer_to_torch, rel_err
+from qeft_amd import qeft_cuda, _lib
+DEV = "cuda:0"
+
+def gemv(n, k, r, g, m, gather=False):
+    b = O.make_layer(n, k, r, g, seed=n + k + m)
+    t = layer_to_torch(b, DEV)
+    x = O.make_activation(m, k, r, seed=m)
+    ids = None
+    if gather:
+        ids = O.sparse_to_dense_ids(np.sort(np.random.default_rng(1).choice(k, size=max(r, 1), replace=False)), k)
+    y = qeft_cuda.gemv_4bit_fused(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                  t.get("oweight_interleaved") if r else None, None,
+                                  torch.from_numpy(ids.astype(np.int32)).to(DEV) if ids is not None else None, None, m, n, k, g)
+    torch.cuda.synchronize()
+    ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g, reorder_ids=ids)
+    assert rel_err(y.cpu().numpy(), ref.astype(np.float64)) < 1e-3, ("gemv", n, k, r, g, m)
+
+def gemm(n, k, r, g, m):
+    b = O.make_layer(n, k, r, g, seed=n + k + m)
+    t = layer_to_torch(b, DEV)
+    x = O.make_activation(m, k, r, seed=m)
+    dy = (np.random.default_rng(m).standard_normal((m, n)) * 0.1).astype(np.float16)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    dx = qeft_cuda.gemm_4bit_dx(torch.from_numpy(dy).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    torch.cuda.synchronize()
+    ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g)
+    assert rel_err(y.cpu().numpy(), ref.astype(np.float64)) < 1e-3, ("gemm", n, k, r, g, m)
+    dx_ref, dow_ref = O.quant_linear_backward(dy, x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, g)
+    assert rel_err(dx.cpu().numpy(), dx_ref.astype(np.float64)) < 2e-3, ("dx", n, k, r, g, m)
+    if r:
+        dow = qeft_cuda.grad_oweight(torch.from_numpy(dy).to(DEV), torch.from_numpy(x).to(DEV), r)
+        torch.cuda.synchronize()
+        assert rel_err(dow.cpu().numpy(), dow_ref) < 1e-3, ("dow", n, k, r, g, m)
+
+# decode GEMV: one row set; K below one 128-k step of INT4 work (only the fp16 slice), exactly one, many; VALU-path shapes
+for (n, k, r, g) in [(16, 128, 0, 128), (16, 256, 128, 128), (16, 384, 128, 128), (8, 128, 64, 64), (8, 64, 0, 32),
+                     (24, 384, 0, 128), (16, 2048, 128, 2048), (16, 4096, 128, 128), (16, 4224, 128, 128), (32, 8192 + 128, 128, 128)]:
+    for m in (1, 2, 7):
+        gemv(n, k, r, g, m)
+gemv(16, 4224, 128, 128, 1, gather=True)
+# row sets that do not divide over the blocks (rs_cap = 3, some blocks own 2) and the grouped / tail-block arithmetic
+for n in (16 * 513, 16 * 769, 16 * 1025):
+    gemv(n, 256, 128, 128, 1)
+# batch slices: 7 rows of K = 11008 do not fit the staging area in one pass
+gemv(64, 11008, 128, 128, 7)
+# GEMM / dX / d(oweight): ragged M and N tiles, the minimum K of the DMA ring, the small-M route, split-K
+for (n, k, r, g, m) in [(136, 192, 0, 64, 129), (8, 64, 0, 64, 1), (264, 256, 128, 128, 17), (128, 1024, 128, 128, 130),
+                        (520, 2048, 64, 128, 257), (256, 4096, 128, 128, 200)]:
+    gemm(n, k, r, g, m)
+print("GUARD-OK")
+'''
+
+
+def test_exact_size_allocations_no_fault_and_correct():
+    env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1")
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and "GUARD-OK" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-4000:])

@@ -52,12 +52,10 @@ def test_pack_oweight_bit_exact(path):
 @pytest.mark.parametrize("path", CASES)
 def test_minmax_and_fakequant_match_reference_quantizer(path):
     d, n, k, r, g, sym, _ = load(path)
-    if sym:
-        pytest.skip("oracle restates the asymmetric min-max branch only")
-    scale, zero = O.minmax_params(d["w_orig"], g)
+    scale, zero = O.minmax_params(d["w_orig"], g, sym=bool(sym))      # both branches of quant.py:142-158
     assert np.array_equal(scale, d["scale"])
     assert np.array_equal(zero, d["zero"])
-    wq = O.fake_quantize(d["w_orig"], scale, zero, g).astype(np.float16)
+    wq = O.fake_quantize(d["w_orig"], scale, zero, g, sym=bool(sym)).astype(np.float16)
     if r:
         wq[:, k - r:] = d["w_orig"][:, k - r:]
     assert np.array_equal(wq.view(np.uint16), d["w_fake"].view(np.uint16))
