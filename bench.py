@@ -1,115 +1,54 @@
 #!/usr/bin/env python3
 """Decode benchmark of the MI355X packed-weight quantized linear path.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): Llama-2-7B shapes, w4 g128 r128, batch 1.  A "step" is ONE decode token of
-the whole model: token begin (embedding row + rotary row), 32 layers x 5 launches (q|k|v grouped GEMV with the RMSNorm
-folded in, rotary+KV-append+attention writing in o_proj's column order, o_proj GEMV + residual, gate|up grouped GEMV
-with the RMSNorm folded in, down_proj GEMV with SiLU*up folded in + residual), final norm, fp16 lm_head, token end
-(greedy argmax, pos += 1) — captured once into a hipGraph and replayed.  Weights are synthetic (seeded), inputs
-are resident in HBM; the timed region is K graph replays bracketed by barrier + synchronize.
+N > 1 may be started either way: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the
+driver's form: RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`, in which case this process
+-- before it makes any GPU call -- starts the N ranks itself as a child `torch.distributed.run` and relays rank 0's line.
 
-N > 1: every quantized linear is row-sharded over the N ranks and one RCCL all-gather per linear rebuilds the
-activations (strong scaling: the model is fixed).
+Workload (BASELINE.json configs[1]): Llama-2-7B shapes, w4 g128 r128, batch 1.  A "step" is ONE decode token of the whole
+model: token begin (embedding row + rotary row), 32 layers x 5 launches (q|k|v GEMV, rotary + KV append + attention,
+o_proj GEMV + residual, gate|up GEMV + SiLU*up, down_proj GEMV + residual; the RMSNorms ride on the producers' epilogues),
+final norm, fp16 lm_head, token end (greedy argmax, pos += 1) -- captured once into a hipGraph and replayed.  Weights are
+synthetic (seeded), inputs are resident in HBM.  Protocol of the reference's generation benchmark (benchmark.py:118-119,
+293-338): a 64-token context is built first (untimed, whatever --warmup is), then W untimed warm-up tokens, then the timed
+region: K graph replays bracketed by barrier + synchronize, max over ranks.
 
 The same JSON line carries
-  roofline      for the dominant kernel (the W4 GEMV): algorithmic bytes of all GEMV launches of one token /
-                their HIP-event-timed duration (the token's GEMV launches replayed back to back from a graph on the
-                launch stream; the event time includes the ~1.3 us inter-kernel gaps, as rocprofv3's kernel-trace
-                durations on this stack do -- the two agree), against 8 TB/s.
-                roofline.traffic = HBM bytes per GEMV launch from the PMC counters: a short child run of this script
-                under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (started before this process touches the GPU),
-                FETCH_SIZE x 1024 x 2 (gfx950 correction); null if rocprofv3 is not available.
-                roofline.per_launch_kind = the same timing, one GEMV of the layer at a time.
-  cpu_baseline  the reference's CPU path (dense nn.Linear on the dequantised weights, oracle/) timed on the host cores
-                for the 7 linears of one layer, scaled to a token.
+  roofline          the dominant kernel (the W4 GEMV): algorithmic bytes of all GEMV launches of one token / their
+                    HIP-event-timed duration (the token's GEMV launches replayed back to back from a graph on the launch
+                    stream; the event time includes the inter-kernel gaps, as rocprofv3's kernel-trace durations on this
+                    stack do), against 8 TB/s.  roofline.traffic: HBM bytes per GEMV launch from a child run under
+                    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (x 1024 x 2, gfx950 correction).  per_launch_kind: the same
+                    timing, one GEMV of the layer at a time.
+  latency_protocol  the reference's per-token protocol (main.py:340-371, benchmark.py:293-338): synchronize after every
+                    token, median / min seconds, tokens/s = 1 / median -- for graph replays and for eager launches.
+  prefill_2048      BASELINE config 3: the M = 2048 MFMA GEMM per 7B shape (us, TFLOP/s, fraction of the 2.5 PFLOP/s dense
+                    fp16 peak, kernel variant) and a whole 2048-token prompt pass.
+  finetune_step     BASELINE config 5 (w4 operands): forward + dX + d(oweight) of one layer at M = 2048 per shape.
+  cpu_baseline      the reference's CPU path (dense nn.Linear on the dequantised weights, oracle/) timed on the host cores:
+                    fp32 and fp16 (the reference's dtype, recon.py:573), m = 1 on the three 7B shapes and M = 2048 on
+                    4096 x 4096; `value` = fp32 tokens/s-equivalent of the linears.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-
-
-def cpu_baseline(shape, reps=8):
-    """Reference CPU path on a bounded sample: one decoder layer's 7 linears, m = 1, fp32 nn.Linear on the
-    dequantised weights.  Returns tokens/s-equivalent = 1 / (n_layers * sum_t)."""
-    import numpy as np
-    from oracle import qeft_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
-    shapes = [(shape.hidden, shape.hidden)] * 4 + [(shape.inter, shape.hidden)] * 2 + [(shape.hidden, shape.inter)]
-    uniq = {}
-    total = 0.0
-    for (n, k) in shapes:
-        if (n, k) not in uniq:
-            bufs = O.make_layer(n, k, shape.n_out, shape.group_size, seed=n + k)
-            w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], shape.group_size)
-            lin = torch.nn.Linear(k, n, bias=False)
-            lin.weight.data = torch.from_numpy(w)
-            x = torch.from_numpy(O.make_activation(1, k, shape.n_out, seed=1).astype(np.float32))
-            with torch.no_grad():
-                for _ in range(2):
-                    lin(x)
-                ts = []
-                for _ in range(reps):
-                    t0 = time.perf_counter()
-                    lin(x)
-                    ts.append(time.perf_counter() - t0)
-            uniq[(n, k)] = sorted(ts)[len(ts) // 2]
-        total += uniq[(n, k)]
-    return {"value": round(1.0 / (shape.n_layers * total), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"7 linears of one {shape.name} layer, m=1, fp32 torch.nn.Linear on oracle-dequantised weights, "
-                      f"median of {reps}; linears only, x{shape.n_layers} layers"}
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline is 2:1 sparse)
+CONTEXT = 64               # benchmark.py:118: tokens in the KV cache before the measured generation starts
+SHAPES_7B = ((4096, 4096), (11008, 4096), (4096, 11008))
 
 
-def hbm_traffic_per_gemv_launch(model_flag, bits):
-    """HBM bytes per GEMV launch from the PMC counters, collected exactly as MI355X_MICROARCH.md prescribes: a run of
-    its own under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (nothing else traced), a short CHILD run of this script
-    started before this process touches the GPU; FETCH_SIZE is in KiB and, on gfx950, reports half of the bytes of a
-    wide streaming read -> x 1024 x 2.  Returns None if the profiler is not there or anything goes wrong."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None
-    # already running under a profiler (e.g. `rocprofv3 --stats -- python3 bench.py`): do not nest another one
-    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None
-    tmp = tempfile.mkdtemp(prefix="qeft_pmc_", dir="/tmp")
-    try:
-        cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "run", "--output-format", "csv", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "4", "--model", model_flag,
-               "--bits", str(bits), "--no-cpu-baseline", "--no-traffic", "--no-per-kind"]
-        env = dict(os.environ, TMPDIR="/tmp")
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
-        vals = []
-        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
-                if r.get("Counter_Name") == "FETCH_SIZE" and "gemv_w4_mfma" in r.get("Kernel_Name", ""):
-                    vals.append(float(r["Counter_Value"]))
-        if not vals:
-            return None
-        return {"bytes_per_launch": int(sum(vals) / len(vals) * 1024 * 2), "launches_sampled": len(vals)}
-    except Exception:
-        return None
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
@@ -122,71 +61,260 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the PMC child run that fills roofline.traffic")
     ap.add_argument("--no-per-kind", action="store_true", help="skip the per-launch-kind timing graphs")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip latency_protocol / prefill_2048 / finetune_step (the decode line and its roofline only)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------- N > 1: self-launch
+def launch_ranks(args):
+    """Parent of a plain `python bench.py --gpus N`: start one rank per GPU as a fresh `torch.distributed.run` child and
+    hand its exit code back.  Nothing here touches the GPU (torch.cuda.device_count() does not initialise it), and the
+    ranks are child processes, never an exec of this one."""
+    import torch
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        # rehearsal on a box with fewer GPUs than ranks: the ranks share the devices, collectives go through gloo (RCCL
+        # refuses two ranks on one device) and run eagerly.  Correctness of the sharded launch sequence, not a measurement.
+        env["QEFT_BENCH_SHARED_GPU"] = str(max(ndev, 1))
+        print(f"[bench] {ndev} GPU(s) visible for --gpus {args.gpus}: rehearsal with shared devices over gloo", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(shape, budget_s=24.0):
+    """Reference CPU path on a bounded sample: dense torch.nn.Linear over the oracle-dequantised
+    weights of the 7B shapes, m = 1 (decode) for all three and M = 2048 (prefill) for 4096 x 4096, in fp32 and in fp16
+    (the reference's dtype).  The time budget bounds the repetitions, never the problem."""
+    import numpy as np
+    import torch
+    from oracle import qeft_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    shapes = sorted({(shape.hidden, shape.hidden), (shape.inter, shape.hidden), (shape.hidden, shape.inter)})
+    counts = {(shape.hidden, shape.hidden): 4, (shape.inter, shape.hidden): 2, (shape.hidden, shape.inter): 1}
+    t_end = time.perf_counter() + budget_s
+    per_shape, total = [], {"fp32": 0.0, "fp16": 0.0}
+
+    def timed(lin, x, max_reps, slice_s):
+        with torch.no_grad():
+            lin(x)
+            ts, t_stop = [], time.perf_counter() + slice_s
+            while len(ts) < max_reps and (len(ts) < 2 or time.perf_counter() < t_stop):
+                t0 = time.perf_counter()
+                lin(x)
+                ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], len(ts)
+
+    for (n, k) in shapes:
+        bufs = O.make_layer(n, k, shape.n_out, shape.group_size, seed=n + k)
+        w = torch.from_numpy(O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"],
+                                             shape.group_size))
+        rec = {"shape": f"{n}x{k}"}
+        for m in ((1, 2048) if (n, k) == (shape.hidden, shape.hidden) else (1,)):
+            x32 = torch.from_numpy(O.make_activation(m, k, shape.n_out, seed=1).astype(np.float32))
+            for dt, tag in ((torch.float32, "fp32"), (torch.float16, "fp16")):
+                lin = torch.nn.Linear(k, n, bias=False, dtype=dt)
+                lin.weight.data = w.to(dt)
+                left = max(t_end - time.perf_counter(), 0.5)
+                t, reps = timed(lin, x32.to(dt), 20 if m == 1 else 3, min(left / 4, 2.0 if m == 1 else 4.0))
+                rec[f"m{m}_{tag}_us"] = round(t * 1e6, 1)
+                rec[f"m{m}_{tag}_GBps"] = round(n * k * (4 if dt == torch.float32 else 2) / t / 1e9, 2)
+                rec[f"m{m}_{tag}_reps"] = reps
+                if m == 1:
+                    total[tag] += counts[(n, k)] * t
+        per_shape.append(rec)
+    return {"value": round(1.0 / (shape.n_layers * total["fp32"]), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "fp16_value": round(1.0 / (shape.n_layers * total["fp16"]), 3),
+            "sample": f"dense torch.nn.Linear on oracle-dequantised weights of the 3 {shape.name} shapes, m=1 (median of <=20 "
+                      f"reps) and M=2048 on {shape.hidden}x{shape.hidden} (<=3 reps), fp32 and fp16; value = 1/(layers x sum "
+                      "of the 7 linears, fp32), fp16_value the same in the reference's dtype",
+            "per_shape": per_shape}
+
+
+# ---------------------------------------------------------------------------------------------------- PMC child run
+def hbm_traffic_per_gemv_launch(model_flag, bits):
+    """HBM bytes per GEMV launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes: a run of its own
+    under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (nothing else traced), a short CHILD run of this script started
+    before this process touches the GPU; FETCH_SIZE is in KiB and, on gfx950, reports half of the bytes of a wide
+    streaming read -> x 1024 x 2.  None if the profiler is not there or anything goes wrong."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    # already running under a profiler (e.g. `rocprofv3 --stats -- python3 bench.py`): do not nest another one
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    tmp = tempfile.mkdtemp(prefix="qeft_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "run", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--model", model_flag,
+               "--bits", str(bits), "--no-cpu-baseline", "--no-traffic", "--no-per-kind", "--no-extras"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        vals = []
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == "FETCH_SIZE" and "gemv_w" in r.get("Kernel_Name", ""):
+                    vals.append(float(r["Counter_Value"]))
+        if not vals:
+            return None
+        return {"bytes_per_launch": int(sum(vals) / len(vals) * 1024 * 2), "launches_sampled": len(vals)}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------- GEMM sub-records
+def _event_time_us(fn, reps, dev):
+    import torch
+    fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(reps):
+        fn()
+    e1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def gemm_records(dev, m=2048, layers=4, reps=10):
+    """prefill_2048.per_shape and finetune_step: forward / dX / d(oweight) of the three 7B shapes at M = 2048, `layers`
+    distinct weight sets cycled so that no launch finds its weights in L2, random (gaussian) activations."""
+    import torch
+    from qeft_amd import _lib, qeft_cuda
+    fwd_recs, ft_recs = [], []
+    r, g = 128, 128
+    for (n, k) in SHAPES_7B:
+        ws = []
+        for _ in range(layers):
+            qw = torch.randint(-32768, 32767, (n // 4, k), dtype=torch.int16, device=dev)
+            sc = (torch.rand(k // g, n, device=dev) * 0.004 + 0.001).half()
+            sz = (-(torch.rand(k // g, n, device=dev) * 8 + 4) * sc.float()).half()
+            ow = (torch.randn(n, r, device=dev) * 0.02).half()
+            ws.append((qw, sc, sz, ow))
+        x = torch.randn(m, k, device=dev).half()
+        dy = torch.randn(m, n, device=dev).half()
+        flops = 2.0 * m * n * k
+        variants = {}
+
+        def fwd():
+            for qw, sc, sz, ow in ws:
+                qeft_cuda.gemm_4bit_qeft(x, qw, sc, sz, ow)
+            variants["fwd"] = _lib.last_variant()
+
+        def dx():
+            for qw, sc, sz, ow in ws:
+                qeft_cuda.gemm_4bit_dx(dy, qw, sc, sz, ow)
+            variants["dx"] = _lib.last_variant()
+
+        def dow():
+            for _ in ws:
+                qeft_cuda.grad_oweight(dy, x, r)
+            variants["dow"] = _lib.last_variant()
+
+        t_f = _event_time_us(fwd, reps, dev) / layers
+        t_x = _event_time_us(dx, reps, dev) / layers
+        t_w = _event_time_us(dow, reps, dev) / layers
+        fwd_recs.append({"shape": f"{n}x{k}", "us": round(t_f, 1), "TFLOPs": round(flops / t_f / 1e6, 1),
+                         "frac_of_peak": round(flops / t_f / 1e6 / MFMA_PEAK_TFLOPS, 4), "variant": variants["fwd"]})
+        ft_recs.append({"shape": f"{n}x{k}", "forward_us": round(t_f, 1), "dx_us": round(t_x, 1), "dow_us": round(t_w, 1),
+                        "step_us": round(t_f + t_x + t_w, 1),
+                        "dx_TFLOPs": round(flops / t_x / 1e6, 1), "dx_frac_of_peak": round(flops / t_x / 1e6 / MFMA_PEAK_TFLOPS, 4),
+                        "step_TFLOPs": round((2 * flops + 2.0 * m * n * r) / (t_f + t_x + t_w) / 1e6, 1),
+                        "variants": dict(variants)})
+        del ws, x, dy
+        torch.cuda.empty_cache()
+    return fwd_recs, ft_recs
+
+
+# ---------------------------------------------------------------------------------------------------- main
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
     # the PMC pass is a child process of its own and has to start BEFORE this process initialises the GPU
     traffic = None
     if world == 1 and "RANK" not in os.environ and not args.no_traffic:
         traffic = hbm_traffic_per_gemv_launch(args.model, args.bits)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+
+    import torch
+    import torch.distributed as dist
+    shared = int(os.environ.get("QEFT_BENCH_SHARED_GPU", "0"))     # rehearsal: ranks share `shared` devices, gloo, eager
+    dev_index = local_rank % shared if shared else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     group = None
-    # QEFT_BENCH_FORCE_TP=1: rehearse the multi-GPU launch sequence (sharded linears + RCCL all-gathers inside the
-    # graph) with a group of one rank on a one-GPU box
+    # QEFT_BENCH_FORCE_TP=1: rehearse the multi-GPU launch sequence (sharded linears + RCCL collectives inside the graph)
+    # with a group of one rank on a one-GPU box
     force_tp = os.environ.get("QEFT_BENCH_FORCE_TP") == "1" and "RANK" in os.environ
     if world > 1 or force_tp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
         group = dist.group.WORLD
 
-    from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, DecodeEngine, QuantLlama, tiny_shape
     import dataclasses
-    base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B, "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
-    shape = dataclasses.replace(base, max_seq=max(512, (args.warmup + args.steps + 8 + 15) // 16 * 16), bits=args.bits)
+    from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, DecodeEngine, QuantLlama, tiny_shape
+    base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B,
+            "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
+    ctx0 = CONTEXT + args.warmup                                   # position of the first timed token
+    shape = dataclasses.replace(base, max_seq=max(512, (ctx0 + args.steps + 8 + 15) // 16 * 16), bits=args.bits)
 
     t_build = time.time()
     model = QuantLlama(shape, dev, seed=0, fast_init=True)
-    eng = DecodeEngine(model, use_graph=not args.no_graph, tp_group=group)
+    eng = DecodeEngine(model, use_graph=not (args.no_graph or shared), tp_group=group)
     eng.greedy = True
     torch.cuda.synchronize(dev)
     t_build = time.time() - t_build
 
-    graph_ok = not args.no_graph
+    graph_ok = eng.use_graph
     if graph_ok:
         try:
             eng.capture()
-            eng.precapture(args.warmup + args.steps + 1)     # one graph per attention split the run will reach
+            eng.precapture(ctx0 + args.steps + 1)     # one graph per attention split the run will reach
         except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             eng.use_graph, eng.graph, eng.graphs, graph_ok = False, None, {}, False
             torch.cuda.synchronize(dev)
 
-    # ---- warm-up: W tokens (they also build the KV-cache context, cf. benchmark.py ctx 64)
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- context (64 tokens, benchmark.py:118) + W warm-up tokens, untimed; then EXACTLY K timed steps
     eng.reset()
     eng.tok.fill_(1)
-    for _ in range(args.warmup):
+    for _ in range(ctx0):
         eng.step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if not shared else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last_tok = int(eng.tok.item())
@@ -195,44 +323,29 @@ def main():
     roof = None
     try:
         g2 = eng.capture(linears_only=True) if graph_ok else None
+        run_lin = (lambda: g2.replay()) if g2 is not None else (lambda: eng._launch_token(True))
         reps = 20
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            g2.replay() if g2 is not None else eng._launch_token(True)
-        torch.cuda.synchronize(dev)
-        e0.record(torch.cuda.current_stream(dev))
-        for _ in range(reps):
-            g2.replay() if g2 is not None else eng._launch_token(True)
-        e1.record(torch.cuda.current_stream(dev))
-        torch.cuda.synchronize(dev)
         launches = 4 * shape.n_layers
-        us_per_launch = e0.elapsed_time(e1) * 1e3 / (reps * launches)
+        us_per_launch = _event_time_us(run_lin, reps, dev) / launches
         bytes_per_launch = eng.weight_bytes_per_token() / launches
         achieved = bytes_per_launch / us_per_launch / 1e3  # GB/s
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel (4 launches per layer)",
-                "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3)}
-        # the same, one GEMV of the layer at a time (32 launches per replay): per-kernel rates for DESIGN.md / rocprof
+                "kernel": f"{eng.gemv_kernel_name()} (4 launches per layer)",
+                "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
+                "frac_of_copy_ceiling_6300": round(achieved / 6300.0, 4)}
         if traffic is not None:
             roof["traffic"] = traffic["bytes_per_launch"]
             roof["traffic_note"] = (f"FETCH_SIZE x 1024 x 2 (gfx950 correction), mean over {traffic['launches_sampled']} "
                                     "GEMV launches of a separate `rocprofv3 --pmc FETCH_SIZE --kernel-trace` child run")
+        # the same, one GEMV of the layer at a time (32 launches per replay): per-kernel rates for DESIGN.md / rocprof
         if g2 is not None and world == 1 and not args.no_per_kind:
             per = {}
             lin0 = eng.lin[0]
             parts = {"qkv": ("q", "k", "v"), "o": ("o",), "gu": ("g", "u"), "d": ("d",)}
             for tag, names in parts.items():
                 gk = eng.capture(linears_only=True, only=tag)
-                for _ in range(3):
-                    gk.replay()
-                torch.cuda.synchronize(dev)
-                e0.record(torch.cuda.current_stream(dev))
-                for _ in range(reps):
-                    gk.replay()
-                e1.record(torch.cuda.current_stream(dev))
-                torch.cuda.synchronize(dev)
-                us = e0.elapsed_time(e1) * 1e3 / (reps * shape.n_layers)
+                us = _event_time_us(gk.replay, reps, dev) / shape.n_layers
                 nbytes = 0
                 for nm in names:
                     l = lin0[nm]
@@ -244,6 +357,60 @@ def main():
         if rank == 0:
             print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
 
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # ---- the reference's per-token protocol: synchronize after every token, median / min, tokens/s = 1 / median
+        try:
+            lat = {}
+            for tag, use_graph in (("hipgraph", True), ("eager", False)):
+                if use_graph and not graph_ok:
+                    continue
+                eng.use_graph = use_graph
+                eng.set_position(ctx0)
+                eng.tok.fill_(1)
+                times = []
+                n_tok = min(args.steps, 64) if not use_graph else args.steps
+                for _ in range(n_tok):
+                    torch.cuda.synchronize(dev)
+                    tick = time.perf_counter()
+                    eng.step()
+                    torch.cuda.synchronize(dev)
+                    times.append(time.perf_counter() - tick)
+                times.sort()
+                med = times[len(times) // 2]
+                lat[tag] = {"median_s": round(med, 7), "min_s": round(times[0], 7), "tokens_per_s": round(1.0 / med, 1),
+                            "tokens": n_tok}
+            eng.use_graph = graph_ok
+            lat["protocol"] = "per-token torch.cuda.synchronize, 1 / median(seconds) (main.py:357-371, benchmark.py:293-338)"
+            extras["latency_protocol"] = lat
+        except Exception as e:
+            print(f"[bench] latency protocol failed: {type(e).__name__}: {e}", file=sys.stderr)
+        # ---- BASELINE configs 3 and 5 at M = 2048 (7B shapes, w4 operands)
+        if args.model == "7b":
+            try:
+                del eng
+                fwd_recs, ft_recs = gemm_records(dev)
+                pre = {"M": 2048, "per_shape": fwd_recs, "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                       "note": "fused-outlier W4 MFMA GEMM, 4 weight sets cycled, gaussian activations"}
+                from qeft_amd.llama import prefill
+                toks = torch.randint(0, shape.vocab, (2048,), device=dev)
+                if shape.max_seq < 2048:
+                    model.shape = dataclasses.replace(shape, max_seq=2048)
+                    half = 64
+                    inv = 1.0 / (shape.rope_theta ** (torch.arange(0, half, dtype=torch.float64) / half))
+                    ang = torch.arange(2048, dtype=torch.float64)[:, None] * inv[None, :]
+                    model.rope_cos, model.rope_sin = ang.cos().float().to(dev), ang.sin().float().to(dev)
+                t_pre = _event_time_us(lambda: prefill(model, toks), 3, dev)
+                lin_flops = 2.0 * 2048 * sum(n * k for n, k in ((4096, 4096),) * 4 + ((11008, 4096),) * 2 + ((4096, 11008),)) * shape.n_layers
+                pre["whole_model"] = {"ms": round(t_pre / 1e3, 2), "tokens_per_s": round(2048 / t_pre * 1e6, 0),
+                                      "linears_TFLOP": round(lin_flops / 1e12, 2),
+                                      "note": "2048-token prompt through every packed linear (GEMM path), torch SDPA attention"}
+                extras["prefill_2048"] = pre
+                extras["finetune_step"] = {"M": 2048, "per_shape": ft_recs,
+                                           "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44)"}
+            except Exception as e:
+                print(f"[bench] GEMM sub-records failed: {type(e).__name__}: {e}", file=sys.stderr)
+
     if rank == 0:
         ms = dt * 1e3 / args.steps
         out = {
@@ -253,13 +420,17 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} w{args.bits} g{shape.group_size} r{shape.n_out} full decode step, batch 1, "
-                                   f"greedy, KV context {args.warmup}..{args.warmup + args.steps} tokens",
+                                   f"greedy, KV context {ctx0}..{ctx0 + args.steps} tokens ({CONTEXT}-token context + "
+                                   f"{args.warmup} warm-up tokens before the timed region)",
                        "layers": shape.n_layers, "hipgraph": graph_ok,
-                       "parallelism": f"tp{world} row-sharded QuantLinear + all-gather" if group is not None else "single GPU",
+                       "parallelism": (f"tp{world}: q/k/v/gate/up row-sharded, o/down column-sharded + one all-reduce each "
+                                       f"(2 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})")
+                       if group is not None else "single GPU",
                        "build_s": round(t_build, 1), "last_token": last_tok},
         }
         if roof:
             out["roofline"] = roof
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(shape)

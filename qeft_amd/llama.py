@@ -391,6 +391,12 @@ class DecodeEngine:
         self.pos.fill_(t)
         self.host_pos = int(t)
 
+    def gemv_kernel_name(self):
+        """The kernel(s) behind the quantized linears of a token (for bench.py's roofline record)."""
+        if self.bits == 3:
+            return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel <BITS = 3>"
+        return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel"
+
     def weight_bytes_per_token(self):
         """Algorithmic HBM bytes of the quantized linears one token streams on THIS rank (SURVEY.md §8d formula)."""
         tot = 0
