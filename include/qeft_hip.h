@@ -175,6 +175,48 @@ int qeft_single_query_attention(const void* q, const void* k, const void* v, con
                                 int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
                                 int n_kv_heads, int max_seq, qeft_stream_t stream);
 
+/* ---- v3 decode linear (batch 1): the decode engine's production GEMV (csrc/gemv_v3.h) ------------------------------
+ *     y[n] = Wdeq . x (+ bias)                                          (gemv_4bit_qeft, gemv_cuda_qeft.cu:392-513, m = 1)
+ * reads the fp16 vector x[k] AS IT IS (no transform of x inside); the decoder's element-wise neighbours sit in the EPILOGUE
+ * of the producing launch instead of the prologue of the consuming one (every block stages x by LDS-DMA and starts its
+ * weight stream at once):
+ *   ssq_in != NULL    x is (v * gamma) of some vector v whose producer also stored n_ssq_in (<= 512) partial sums of v^2
+ *                     (readable up to a multiple of 4 floats): y *= rsqrt(sum(ssq_in) / k + eps) -- together the RMSNorm of
+ *                     layernorm.cu:26-76 in front of W
+ *   mode 1 (PAIR)     the operand's rows are pair-interleaved -- rows [16g, 16g+8) are gate_proj rows [8g, 8g+8), rows
+ *                     [16g+8, 16g+16) the same rows of up_proj (a derived buffer, see qeft_amd/fuse.py):
+ *                     y[8g + i] = silu(fp16 gate_i) * fp16 up_i, n/2 outputs (the arithmetic of qeft_silu_mul)
+ *   residual != NULL  (mode 0) the fp32 residual stream: `residual` and `y` are FLOAT vectors, y = Wx + residual (in place is fine)
+ *   gamma_out != NULL (with residual) additionally y_norm = fp16(y * gamma_out) and ssq_out[b] = the sum of y^2 over the rows
+ *                     of block b, b < qeft_decode_linear_blocks(n): what the NEXT launch takes as x / ssq_in.
+ * Operands: qweight int16 [n/4, k]; sz_packed from qeft_pack_scales (required); oweight PLAIN fp16 [n, 128] (the `oweight`
+ * buffer of the checkpoint, not the interleaved copy; NULL when n_out == 0); bias optional.  Several linears that read the
+ * same x (q|k|v) are ONE operand: their buffers concatenated along n at load time.
+ * Requirements: k % 128 == 0, n_out in {0, 128}, group 128 or k, n % 16 == 0.
+ * qeft_gemv_v3_check_extents: CPU-only self-check -- enumerates every address the kernel would form for the configuration
+ * and returns how many leave their operand (0 = none; -1 = configuration not accepted); shrink_rows > 0 is the negative
+ * control (operands that many rows shorter than the geometry: the count must be positive). */
+int qeft_decode_linear_blocks(int n_rows);
+int qeft_decode_linear(const void* x, const void* qweight, const void* sz_packed, const void* oweight, const void* bias,
+                       void* y, int n, int k, int group_size, int n_out, int mode, const void* residual,
+                       const float* ssq_in, int n_ssq_in, float eps, const void* gamma_out, void* y_norm, float* ssq_out,
+                       qeft_stream_t stream);
+long long qeft_gemv_v3_check_extents(int n, int k, int group_size, int n_out, int n_ssq_in, int shrink_rows);
+
+/* Producer-form helpers for the same scheme.
+ * qeft_token_begin_norm: qeft_token_begin + h32 = float(embed[*tok]), h_norm = fp16(embed[*tok] * gamma),
+ *                        ssq_out[b] (b < qeft_token_begin_norm_blocks(hidden)) = partial sums of squares.
+ * qeft_residual_norm:    h_out(fp32) = h(fp32) (+ add(fp16)); with gamma: h_norm = fp16(h_out * gamma), ssq_out[b] likewise
+ *                        (tensor-parallel path: the residual add follows an all-reduce; also the stand-alone reference form
+ *                        the fused epilogues are tested against). */
+int qeft_token_begin_norm_blocks(int hidden);
+int qeft_token_begin_norm(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h32, void* rope_row,
+                          const void* gamma, void* h_norm, float* ssq_out, int hidden, int vocab, int max_seq,
+                          qeft_stream_t stream);
+int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hidden, float eps, qeft_stream_t stream); /* qeft_rmsnorm on an fp32 input */
+int qeft_residual_norm(const void* h32, const void* add, const void* gamma, void* h32_out, void* h_norm, float* ssq_out,
+                       int hidden, qeft_stream_t stream);
+
 /* ---- 3-bit EXTENSION (BASELINE config 5).  The reference cannot pack or run 3 bits (QuantLinear asserts
  * bits == 4, qlinear.py:127; its quantiser can produce them, quant.py:8-10 with maxq = 7), so the layout is this
  * library's own, shaped by the decode GEMV (oracle/qeft_oracle.py: pack_w3 / w3_position):

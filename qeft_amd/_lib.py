@@ -47,6 +47,13 @@ SIGNATURES = {
     "qeft_attn_workspace_bytes": [_i, _i],
     "qeft_token_begin": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_token_end": [_p, _p, _p, _i, _i, _p],
+    "qeft_decode_linear_blocks": [_i],
+    "qeft_decode_linear": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, ctypes.c_float, _p, _p, _p, _p],
+    "qeft_gemv_v3_check_extents": [_i, _i, _i, _i, _i, _i],
+    "qeft_token_begin_norm_blocks": [_i],
+    "qeft_token_begin_norm": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_rmsnorm_f32": [_p, _p, _p, _i, _i, ctypes.c_float, _p],
+    "qeft_residual_norm": [_p, _p, _p, _p, _p, _p, _i, _p],
     "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
 }
@@ -71,7 +78,8 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name in ("qeft_error_string", "qeft_last_variant") else
-                          ctypes.c_longlong if name in ("qeft_gemm_w4_workspace_bytes", "qeft_gemm_w4_dx_workspace_bytes") else _i)
+                          ctypes.c_longlong if name in ("qeft_gemm_w4_workspace_bytes", "qeft_gemm_w4_dx_workspace_bytes",
+                                                       "qeft_gemv_v3_check_extents") else _i)
         _lib = l
     return _lib
 

@@ -4,8 +4,20 @@
 
 #include "../../include/qeft_hip.h"
 #include "qeft_common.h"
+#include "gemv_v3.h"
 
 namespace qeft {
+hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st);
+int gemv_v3_blocks(int nsets);
+bool gemv_v3_ok(int K, int G, int n_out);
+long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in);
+hipError_t token_begin_norm_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
+                                   void* rope_row, const void* gamma, void* hnorm, float* ssq_out, int hidden, int vocab,
+                                   int max_seq, hipStream_t st);
+int token_begin_norm_blocks(int hidden);
+hipError_t residual_norm_launch(const void* h, const void* add, const void* gamma, void* h_out, void* hnorm, float* ssq_out,
+                                int hidden, hipStream_t st);
+hipError_t rmsnorm_f32_launch(const void* x, const void* gamma, void* y, int m, int H, float eps, hipStream_t st);
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
 hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
 hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st);
@@ -399,6 +411,13 @@ int qeft_rmsnorm(const void* x, const void* add, const void* gamma, void* res_ou
     return finish(qeft::rmsnorm_launch(x, add, gamma, res_out, y, m, hidden, eps, (hipStream_t)stream));
 }
 
+int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hidden, float eps, qeft_stream_t stream) {
+    if (m < 1 || hidden < 8 || hidden % 8 != 0) return QEFT_ERR_SHAPE;
+    if (!x32 || !gamma || !y) return QEFT_ERR_NULL;
+    if (!aligned16(x32) || !aligned16(y) || !aligned16(gamma)) return QEFT_ERR_ALIGN;
+    return finish(qeft::rmsnorm_f32_launch(x32, gamma, y, m, hidden, eps, (hipStream_t)stream));
+}
+
 int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_stream_t stream) {
     if (n < 8 || n % 8 != 0) return QEFT_ERR_SHAPE;
     if (!gate || !up || !out) return QEFT_ERR_NULL;
@@ -437,6 +456,84 @@ int qeft_single_query_attention(const void* q, const void* k, const void* v, con
     if (!aligned16(k_cache_ft) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
     return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache_ft, v_cache, pos, nullptr, out, nullptr,
                                                 n_heads, n_kv_heads, max_seq, 1, tab_rows, (hipStream_t)stream, true));
+}
+
+// ---- v3 decode linear (gemv_v3.h): fills the geometry, validates, launches
+static int v3_geom(qeft::V3Geom& G, int n, int k, int group_size, int n_out, int mode) {
+    if (mode != qeft::V3_MODE_PLAIN && mode != qeft::V3_MODE_PAIR) return QEFT_ERR_SHAPE;
+    if (n <= 0 || n % 16 != 0) return QEFT_ERR_SHAPE;
+    if (k <= 0 || group_size <= 0 || k % group_size != 0) return QEFT_ERR_GROUP;
+    if (!qeft::gemv_v3_ok(k, group_size, n_out)) return QEFT_ERR_SHAPE;
+    G.K = k;
+    G.n_out = n_out;
+    G.nsteps = k / 128;
+    G.nfull = (k - n_out) / 128;
+    G.ngroups = group_size == k ? 1 : k / 128;
+    G.nsets = n / 16;
+    return QEFT_OK;
+}
+
+int qeft_decode_linear_blocks(int n_rows) {
+    if (n_rows <= 0 || n_rows % 16 != 0) return 0;
+    return qeft::gemv_v3_blocks(n_rows / 16);
+}
+
+int qeft_decode_linear(const void* x, const void* qweight, const void* sz_packed, const void* oweight, const void* bias,
+                       void* y, int n, int k, int group_size, int n_out, int mode, const void* residual,
+                       const float* ssq_in, int n_ssq_in, float eps, const void* gamma_out, void* y_norm, float* ssq_out,
+                       qeft_stream_t stream) {
+    if (!x || !qweight || !sz_packed || !y || (n_out > 0 && !oweight)) return QEFT_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(sz_packed) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
+    qeft::V3Args a{};
+    if (int e = v3_geom(a.g, n, k, group_size, n_out, mode)) return e;
+    if ((residual || gamma_out) && mode != qeft::V3_MODE_PLAIN) return QEFT_ERR_SHAPE;
+    if (gamma_out && (!residual || !y_norm || !ssq_out)) return QEFT_ERR_NULL;
+    if ((residual && !aligned16(residual)) || (gamma_out && !aligned16(gamma_out))) return QEFT_ERR_ALIGN;
+    if (ssq_in && (n_ssq_in < 1 || n_ssq_in > qeft::V3_MAX_SSQ || !aligned16(ssq_in))) return QEFT_ERR_SHAPE;
+    a.x = (const qeft::f16*)x;
+    a.qw = (const uint8_t*)qweight;
+    a.szp = (const uint8_t*)sz_packed;
+    a.ow = (const uint8_t*)oweight;
+    a.bias = (const qeft::f16*)bias;
+    a.residual = (const float*)residual;
+    a.y = residual ? nullptr : (qeft::f16*)y;
+    a.y32 = residual ? (float*)y : nullptr;
+    a.ssq_in = ssq_in;
+    a.n_ssq_in = ssq_in ? n_ssq_in : 0;
+    a.eps = eps;
+    a.gamma_out = (const qeft::f16*)gamma_out;
+    a.ynorm = (qeft::f16*)y_norm;
+    a.ssq_out = ssq_out;
+    return finish(qeft::gemv_v3_launch(a, mode, (hipStream_t)stream));
+}
+
+long long qeft_gemv_v3_check_extents(int n, int k, int group_size, int n_out, int n_ssq_in, int shrink_rows) {
+    qeft::V3Geom G{};
+    if (v3_geom(G, n, k, group_size, n_out, qeft::V3_MODE_PLAIN) != QEFT_OK) return -1;
+    if (n_ssq_in < 0 || n_ssq_in > qeft::V3_MAX_SSQ) return -1;
+    return qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in);
+}
+
+int qeft_token_begin_norm_blocks(int hidden) { return hidden >= 8 ? qeft::token_begin_norm_blocks(hidden) : 0; }
+
+int qeft_token_begin_norm(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h, void* rope_row,
+                          const void* gamma, void* h_norm, float* ssq_out, int hidden, int vocab, int max_seq,
+                          qeft_stream_t stream) {
+    if (hidden < 8 || hidden % 8 != 0 || vocab < 1 || max_seq < 1) return QEFT_ERR_SHAPE;
+    if (!embed || !tok || !h || !gamma || !h_norm || !ssq_out || (rope_row && (!rope_tab || !pos))) return QEFT_ERR_NULL;
+    if (!aligned16(embed) || !aligned16(h) || !aligned16(gamma) || !aligned16(h_norm)) return QEFT_ERR_ALIGN;
+    return finish(qeft::token_begin_norm_launch(embed, tok, rope_tab, pos, h, rope_row, gamma, h_norm, ssq_out, hidden, vocab,
+                                                max_seq, (hipStream_t)stream));
+}
+
+int qeft_residual_norm(const void* h, const void* add, const void* gamma, void* h_out, void* h_norm, float* ssq_out,
+                       int hidden, qeft_stream_t stream) {
+    if (hidden < 8 || hidden % 8 != 0) return QEFT_ERR_SHAPE;
+    if (!h || !h_out) return QEFT_ERR_NULL;
+    if (gamma && (!h_norm || !ssq_out)) return QEFT_ERR_NULL;
+    if (!aligned16(h) || !aligned16(h_out) || (add && !aligned16(add)) || (gamma && (!aligned16(gamma) || !aligned16(h_norm))))
+        return QEFT_ERR_ALIGN;
+    return finish(qeft::residual_norm_launch(h, add, gamma, h_out, h_norm, ssq_out, hidden, (hipStream_t)stream));
 }
 
 int qeft_token_begin(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h, void* rope_row,

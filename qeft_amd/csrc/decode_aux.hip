@@ -410,6 +410,84 @@ __global__ __launch_bounds__(256) void token_begin_kernel(const f16* __restrict_
     }
 }
 
+// begin + the first layer's RMSNorm in the producer form the v3 GEMV consumes: hnorm = fp16(h * gamma), ssq_out[block] =
+// this block's sum of h^2 (the consumer multiplies its outputs by rsqrt(sum / hidden + eps)).  grid = ceil(hidden / 2048).
+__global__ __launch_bounds__(256) void token_begin_norm_kernel(const f16* __restrict__ embed, const long long* __restrict__ tok,
+                                                               const float* __restrict__ rope_tab, const int* __restrict__ pos,
+                                                               float* __restrict__ h, float* __restrict__ rope_row,
+                                                               const f16* __restrict__ gamma, f16* __restrict__ hnorm,
+                                                               float* __restrict__ ssq_out, int hidden, int vocab, int max_seq) {
+    __shared__ float sm[4];
+    const long long tk = min(max(*tok, 0ll), (long long)vocab - 1);
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    float ss = 0.f;
+    if (i < hidden) {
+        const h8 v = *(const h8*)(embed + (size_t)tk * hidden + i), g = *(const h8*)(gamma + i);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ss += (float)v[j] * (float)v[j];
+            o[j] = (f16)((float)v[j] * (float)g[j]);
+            h[i + j] = (float)v[j];
+        }
+        *(h8*)(hnorm + i) = o;
+    }
+    ss = block_sum_256(ss, sm);
+    if (threadIdx.x == 0) ssq_out[blockIdx.x] = ss;
+    if (blockIdx.x == 0 && threadIdx.x < 128 && rope_row) {
+        const int p = min(max(*pos, 0), max_seq - 1);
+        rope_row[threadIdx.x] = rope_tab[(size_t)p * 128 + threadIdx.x];
+    }
+}
+
+// h_out = h (+ add); with gamma: hnorm = fp16(h_out * gamma), ssq_out[block] = this block's sum of h_out^2.  The stand-alone
+// form of what the v3 GEMV epilogue emits (tensor-parallel path: the residual add follows an all-reduce).  grid = ceil(hidden / 2048).
+__global__ __launch_bounds__(256) void residual_norm_kernel(const float* __restrict__ h, const f16* __restrict__ add,
+                                                            const f16* __restrict__ gamma, float* __restrict__ h_out,
+                                                            f16* __restrict__ hnorm, float* __restrict__ ssq_out, int hidden) {
+    __shared__ float sm[4];
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    float ss = 0.f;
+    if (i < hidden) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = h[i + j];
+        if (add) {
+            const h8 w = *(const h8*)(add + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)w[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h_out[i + j] = v[j];
+        if (gamma) {
+            const h8 g = *(const h8*)(gamma + i);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ss += v[j] * v[j];
+                o[j] = (f16)(v[j] * (float)g[j]);
+            }
+            *(h8*)(hnorm + i) = o;
+        }
+    }
+    if (gamma) {
+        ss = block_sum_256(ss, sm);
+        if (threadIdx.x == 0) ssq_out[blockIdx.x] = ss;
+    }
+}
+
+// y[m][H] (fp16) = rmsnorm(x[m][H] fp32) * gamma: the final norm of the decode engine, whose residual stream is fp32.
+__global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restrict__ x, const f16* __restrict__ gamma,
+                                                          f16* __restrict__ y, int H, float eps) {
+    __shared__ float sm[4];
+    const size_t base = (size_t)blockIdx.x * H;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) ss += x[base + i] * x[base + i];
+    ss = block_sum_256(ss, sm);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    for (int i = threadIdx.x; i < H; i += 256) y[base + i] = (f16)(x[base + i] * rs * (float)gamma[i]);
+}
+
 // end: tok = argmax(logits) when greedy (lowest index among equal maxima, like torch.argmax), pos += 1.  One block.
 __global__ __launch_bounds__(1024) void token_end_kernel(const f16* __restrict__ logits, long long* __restrict__ tok,
                                                          int* __restrict__ pos, int vocab, int greedy) {
@@ -451,6 +529,29 @@ hipError_t token_begin_launch(const void* embed, const void* tok, const void* ro
                               void* rope_row, int hidden, int vocab, int max_seq, hipStream_t st) {
     hipLaunchKernelGGL(token_begin_kernel, dim3((hidden / 8 + 255) / 256), dim3(256), 0, st, (const f16*)embed,
                        (const long long*)tok, (const float*)rope_tab, pos, (f16*)h, (float*)rope_row, hidden, vocab, max_seq);
+    return hipGetLastError();
+}
+
+int token_begin_norm_blocks(int hidden) { return (hidden / 8 + 255) / 256; }
+
+hipError_t token_begin_norm_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
+                                   void* rope_row, const void* gamma, void* hnorm, float* ssq_out, int hidden, int vocab,
+                                   int max_seq, hipStream_t st) {
+    hipLaunchKernelGGL(token_begin_norm_kernel, dim3(token_begin_norm_blocks(hidden)), dim3(256), 0, st, (const f16*)embed,
+                       (const long long*)tok, (const float*)rope_tab, pos, (float*)h, (float*)rope_row, (const f16*)gamma,
+                       (f16*)hnorm, ssq_out, hidden, vocab, max_seq);
+    return hipGetLastError();
+}
+
+hipError_t residual_norm_launch(const void* h, const void* add, const void* gamma, void* h_out, void* hnorm, float* ssq_out,
+                                int hidden, hipStream_t st) {
+    hipLaunchKernelGGL(residual_norm_kernel, dim3(token_begin_norm_blocks(hidden)), dim3(256), 0, st, (const float*)h,
+                       (const f16*)add, (const f16*)gamma, (float*)h_out, (f16*)hnorm, ssq_out, hidden);
+    return hipGetLastError();
+}
+
+hipError_t rmsnorm_f32_launch(const void* x, const void* gamma, void* y, int m, int H, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(m), dim3(256), 0, st, (const float*)x, (const f16*)gamma, (f16*)y, H, eps);
     return hipGetLastError();
 }
 

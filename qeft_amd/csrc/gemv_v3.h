@@ -1,0 +1,378 @@
+// Decode GEMV, third formulation ("v3"): the batch-1 production path of the decode engine.
+//
+// Same MFMA mapping as gemv_w4_mfma.h (one wave-wide 16 B/lane load = 16 rows x 128 k = four B fragments of
+// v_mfma_f32_16x16x32_f16, x as the A operand from LDS), but the per-block prologue is gone.  Round 1 measured the launch as
+// T = 4.3 us + bytes / 5.9 TB/s with no wasted traffic: the fixed cost was ~450 prologue instructions every one of the
+// 256-768 blocks executed (x pre-scaling, per-step correction sums, RMSNorm / SiLU on the staged vector, the outlier-slab
+// de-interleave) in front of a staging barrier.  Here:
+//
+//   * x is consumed RAW.  Nibble pairs still become 1024 + q / 1024 + 16 q with one v_and_or_b32 each, but instead of
+//     pre-scaling x and pre-computing per-step sums, the bias is removed on the otherwise idle matrix pipe: with the
+//     constant fragment c = -1024,
+//         P_lo = x_lo.(1024 + q),  A_lo = x_lo.c = -1024 S_lo        (k with low nibbles,  2 MFMAs each)
+//         P_hi = x_hi.(1024 + 16 q), A_hi = x_hi.c = -1024 S_hi      (k with high nibbles, 2 MFMAs each)
+//         acc += s * ((P_lo + A_lo) + (P_hi + A_hi) / 16) + sz * (-(A_lo + A_hi) / 1024)
+//     8 MFMAs + ~8 VALU per step instead of 4 MFMAs + LDS-resident sums; fp32 accumulation as before.
+//   * everything a block stages -- x, its (scale | scaled_zero) words, its fp16 outlier rows, the epilogue's residual /
+//     gamma values, the producer's partial sums of squares -- reaches LDS by LDS-DMA (global_load_lds, 16 B/lane, no VGPR
+//     round trip, no VALU) issued in front of the weight ring; there is NO compiler-visible global load in front of the
+//     ring, and every kernel argument is read in one batch of scalar loads behind one wait.
+//   * the transforms moved to the PRODUCER's epilogue, where they touch 16-64 values per block instead of K:
+//       RMSNorm:  the producer of h also stores fp16(h * gamma) and its block's partial sum of squares; the consumer
+//                 multiplies its outputs by rsqrt(sum / K + eps)  (W.(h gamma rs) = rs W.(h gamma), as in round 1);
+//       SiLU*up:  PAIR mode: the operand's rows are stored pair-interleaved (8 gate rows, 8 up rows per 16-row MFMA set;
+//                 a derived buffer built once at load time, qeft_amd/fuse.py), so the block that finishes a set holds
+//                 both halves and stores silu(gate) * up directly.
+//   * one operand per launch: q|k|v are concatenated at load time, so the kernel has no per-part logic.
+//   * the outlier step takes its B fragments from the PLAIN oweight [N, r] rows (64 contiguous bytes per lane, gathered by
+//     the DMA into an XOR-swizzled LDS image), not from oweight_interleaved.
+//
+// Address arithmetic lives in __host__ __device__ functions shared with a host-side enumerator
+// (qeft_gemv_v3_check_extents, capi.hip) that walks every block / wave / lane / piece / step of a configuration and
+// checks each access against the operand sizes on the CPU (tests/test_gemv_v3_extents.py): the unconditional, clamped
+// loads this design relies on are exactly where the round-1 faults came from.
+#pragma once
+#include "qeft_common.h"
+
+namespace qeft {
+
+constexpr int V3_NW = 8;        // waves per block; wave w owns the 128-k steps w, w + 8, ... of each of its row sets
+constexpr int V3_MAX_RS = 4;    // 16-row sets per block (LDS is carved for rs_cap <= 4)
+constexpr int V3_MAX_SSQ = 512; // partial sums of squares a consumer accepts
+constexpr int V3_MODE_PLAIN = 0;
+constexpr int V3_MODE_PAIR = 1; // rows pair-interleaved: set g = gate rows [8g, 8g+8) then up rows [8g, 8g+8); y[8g + i] = silu(gate) * up
+
+struct V3Geom {
+    int K, n_out, nsteps, nfull, ngroups, nsets;   // nsets = N / 16
+};
+
+struct V3Args {
+    const f16* x;           // [K] fp16, consumed as it is
+    const uint8_t* qw;      // int16 [N/4][K] checkpoint layout
+    const uint8_t* szp;     // u32 [N/16][ngroups][16] (scale | scaled_zero << 16), qeft_pack_scales
+    const uint8_t* ow;      // fp16 [N][128] plain outlier rows (unused when n_out == 0)
+    const float* ssq_in;    // optional: n_ssq_in partial sums of squares of the vector x was derived from (x = v * gamma)
+    const float* residual;  // optional (PLAIN): the fp32 residual stream; y32 = acc + residual (fp32 out, may alias)
+    const f16* gamma_out;   // optional (PLAIN, with residual): ynorm = fp16(y * gamma_out), ssq_out[block] = sum of y^2 over its rows
+    V3Geom g;
+    int rs_cap, nblk;       // LDS row sets per block, grid size (read from here, not from the dispatch packet)
+    int sets_q, sets_r;     // nsets / grid, nsets % grid (host-side division: the kernel deals sets without dividing)
+    int n_ssq_in;
+    float eps;
+    const f16* bias;        // optional [N] (PAIR: in the interleaved row order)
+    f16* y;                 // PLAIN without residual: [N]; PAIR: [N/2]
+    float* y32;             // PLAIN with residual: [N]
+    f16* ynorm;
+    float* ssq_out;
+};
+
+// ---- LDS carve-up (bytes); every DMA-filled region is a whole number of 1 KB pieces
+__host__ __device__ constexpr int v3_x_bytes(int K) { return (K * 2 + 1023) / 1024 * 1024; }
+__host__ __device__ constexpr int v3_sz_bytes(int ngroups) { return (ngroups * 64 + 1023) / 1024 * 1024; }   // per row set
+__host__ __device__ constexpr size_t v3_smem_bytes(int K, int ngroups, int n_out, int rs_cap) {
+    return (size_t)v3_x_bytes(K) + (size_t)rs_cap * v3_sz_bytes(ngroups) + (n_out > 0 ? (size_t)rs_cap * 4096 : 0) +
+           1024 /* epilogue operands */ + 2048 /* ssq_in */ + (size_t)rs_cap * V3_NW * 16 * 4 + 64;
+}
+
+// ---- source byte offsets of every load (relative to the operand's base)
+// weights of (set g, lane row nl, 32-k chunk kc): row-group base, and the lane's offset inside it (+ 256 per step)
+__host__ __device__ inline size_t v3_w_set_off(const V3Geom& G, int g) { return (size_t)g * 4 * G.K * 2; }
+__host__ __device__ inline uint32_t v3_w_lane_off(const V3Geom& G, int nl, int kc) {
+    return (uint32_t)(nl >> 2) * (uint32_t)G.K * 2u + (uint32_t)(kc >> 1) * 128u + (uint32_t)(nl & 3) * 32u + (uint32_t)(kc & 1) * 16u;
+}
+__host__ __device__ inline uint32_t v3_last_step_off(const V3Geom& G) { return (uint32_t)G.K * 2u - 256u; }
+// x piece i: the lane's 16 source bytes, clamped (the LDS destination is lane-linear; clamped lanes fill padding)
+__host__ __device__ inline uint32_t v3_x_off(const V3Geom& G, int piece, int lane) {
+    const uint32_t o = (uint32_t)piece * 1024u + (uint32_t)lane * 16u, last = (uint32_t)G.K * 2u - 16u;
+    return o < last ? o : last;
+}
+// scale piece j of set g: the set's words are one contiguous run of ngroups * 64 bytes
+__host__ __device__ inline size_t v3_sz_off(const V3Geom& G, int g, int j, int lane) {
+    const uint32_t o = (uint32_t)j * 1024u + (uint32_t)lane * 16u, last = (uint32_t)G.ngroups * 64u - 16u;
+    return (size_t)g * G.ngroups * 64 + (o < last ? o : last);
+}
+// outlier piece j of set g: lane = (row 4j + lane/16, LDS chunk lane%16 <- global chunk (lane%16) ^ row)
+__host__ __device__ inline size_t v3_ow_off(int g, int j, int lane) {
+    const int row = 4 * j + (lane >> 4), cc = (lane & 15) ^ row;
+    return ((size_t)(g * 16 + row) * 128 + cc * 8) * 2;
+}
+// epilogue operands, one piece: lanes [0, 4 RS) = residual (4 floats of the block's rows each), lanes [16, 16 + 2 RS) =
+// gamma_out (8 halves each); every other lane re-reads lane 0's / lane 16's vector.  Byte offset into the respective vector.
+__host__ __device__ inline size_t v3_epi_off(int set0, int RS, int lane) {
+    if (lane < 16) return ((size_t)set0 * 16 + (size_t)(lane < 4 * RS ? lane : 0) * 4) * 4;         // residual (fp32)
+    const int l = lane - 16;
+    return ((size_t)set0 * 16 + (size_t)(l < 2 * RS ? l : 0) * 8) * 2;                               // gamma_out (fp16)
+}
+
+// Row sets [0, nsets) dealt to the blocks as evenly as possible: the first r blocks get q + 1 (q = nsets / nblk, r = nsets % nblk)
+__host__ __device__ inline void v3_block_sets(int b, int q, int r, int& set0, int& cnt) {
+    set0 = b * q + (b < r ? b : r);
+    cnt = q + (b < r ? 1 : 0);
+}
+// Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share an L2); neighbouring sets share scale / outlier lines.
+__host__ __device__ inline int v3_xcd_block(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+#if defined(__HIPCC__)
+typedef _Float16 v3h8 __attribute__((ext_vector_type(8)));
+
+// LDS-DMA of one 1 KB piece: lane's 16 bytes at gsrc -> LDS[lds_dst + 16 * lane].  Hidden from hipcc's s_waitcnt
+// bookkeeping on purpose (guide 5.7): the pieces are OLDER than every ring load, so the compiler's counted waits for the
+// ring cover them, and the one wait that matters (before the staging barrier) is placed by hand.
+__device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int D, bool OUTL, int MODE>
+__global__ __launch_bounds__(V3_NW * 64) void gemv_v3_kernel(V3Args a) {
+    static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
+    // every argument the prologue needs is copied to registers here, in one batch of scalar loads behind ONE wait: argument
+    // loads that hipcc leaves next to their first use each cost a dependent scalar-memory round trip
+    V3Geom G = a.g;
+    const int rs_cap = a.rs_cap, nblk = a.nblk, sets_q = a.sets_q, sets_r = a.sets_r, ssq_n = a.n_ssq_in;
+    const float eps = a.eps;
+    const f16* const bias = a.bias;
+    f16* const yout = a.y;
+    float* const y32 = a.y32;
+    f16* const ynorm = a.ynorm;
+    float* const ssq_out = a.ssq_out;
+    const uint8_t* const xptr = (const uint8_t*)a.x;
+    const uint8_t* const qw = a.qw;
+    const uint8_t* const szp = a.szp;
+    const uint8_t* const ow = a.ow;
+    const uint8_t* const ssq_in = (const uint8_t*)a.ssq_in;
+    const uint8_t* const residual = (const uint8_t*)a.residual;
+    const uint8_t* const gamma_out = (const uint8_t*)a.gamma_out;
+    asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(G.nsteps), "s"(rs_cap), "s"(nblk), "s"(sets_q), "s"(sets_r),
+                 "s"(ssq_n), "s"(xptr), "s"(qw), "s"(szp), "s"(ow), "s"(ssq_in), "s"(residual), "s"(gamma_out));
+    asm volatile("" ::"s"(eps), "s"(bias), "s"(yout), "s"(y32), "s"(ynorm), "s"(ssq_out));
+
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
+    const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups);
+    uint8_t* xs = smem;                                               // [K] fp16 raw (+ padding to 1 KB)
+    uint8_t* szl = xs + XB;                                           // [rs_cap][SZB / 64][16] u32
+    uint8_t* owl = szl + rs_cap * SZB;                                // [rs_cap][16 rows][16 chunks ^ row][8] fp16
+    uint8_t* epl = owl + (OUTL ? rs_cap * 4096 : 0);                  // [64 lanes][16 B]: residual | gamma_out of the block's rows
+    float* ssql = (float*)(epl + 1024);                               // [512] ssq_in
+    float* red = ssql + V3_MAX_SSQ;                                   // [rs_cap][8 waves][16]
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 15, kc = lane >> 4;
+    int set0, RS;
+    v3_block_sets(v3_xcd_block(blockIdx.x, nblk), sets_q, sets_r, set0, RS);
+
+    // ---- 1. staging by LDS-DMA.  x: waves 0..7 take pieces w, w + 8, ..; per row set the scale words (piece j = wave) and
+    //         the outlier rows (waves 4..7, piece wave - 4).  No VGPR destination, no VALU on the data, nothing to wait for
+    //         until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
+    const int PX = XB >> 10, SPS = SZB >> 10;
+    for (int p = wave; p < PX; p += V3_NW)
+        v3_dma16(xptr + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 10)));
+    for (int rs = 0; rs < RS; ++rs) {
+        for (int j = wave; j < SPS; j += V3_NW)
+            v3_dma16(szp + v3_sz_off(G, set0 + rs, j, lane),
+                     __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)XB + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
+        if (OUTL && wave >= 4)
+            v3_dma16(ow + v3_ow_off(set0 + rs, wave - 4, lane),
+                     __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - 4) << 10)));
+    }
+
+    // ---- 2. weight stream: ring of D steps per wave, branch-free, oldest first.  The wave's work is the sequence
+    //         t = 0 .. RS*nsw-1 of (row set t / nsw, step wave + 8 (t % nsw)); issues past the end re-read a valid address.
+    const int nsw = (G.nfull - wave + V3_NW - 1) / V3_NW;
+    const uint32_t last_off = v3_last_step_off(G);
+    const uint8_t* const wbase = qw + v3_w_set_off(G, set0);         // wave-uniform
+    const uint32_t lane_off = v3_w_lane_off(G, nl, kc);
+    const uint32_t set_bytes = (uint32_t)G.K * 8u;                   // one 16-row set = 4 row groups of 2 K bytes
+    u32x4 ring[D];
+    int p_rs = 0, p_i = 0;
+    auto issue = [&](u32x4& b) {
+        const uint8_t* sp = wbase + ((size_t)p_rs * set_bytes + min((uint32_t)(wave + p_i * V3_NW) * 256u, last_off));   // uniform
+        b = __builtin_nontemporal_load((const u32x4*)(sp + lane_off));
+        if (++p_i >= nsw) { p_i = 0; if (p_rs < RS - 1) ++p_rs; }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        issue(ring[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- 3. staged data complete: this wave's pieces are older than its D ring loads
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+    // ---- 2b. epilogue-only operands, requested BEHIND the ring (they must not delay the weight stream): wave 1 the
+    //          residual / gamma_out values of the block's rows, waves 2 and 3 the producer's partial sums of squares.  They
+    //          complete before the vmcnt(0) every wave executes in front of the final barrier.
+    if (MODE == V3_MODE_PLAIN && residual && wave == 1) {
+        const bool g_lane = lane >= 16 && gamma_out != nullptr;
+        v3_dma16((g_lane ? gamma_out : residual) + v3_epi_off(set0, RS, g_lane ? lane : (lane < 16 ? lane : 0)),
+                 __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)epl));
+    }
+    if (ssq_in && (wave == 2 || wave == 3) && (wave - 2) * 256 < ssq_n) {       // <= 2 pieces of 256 floats
+        const int v = min((wave - 2) * 64 + lane, (ssq_n - 1) >> 2);             // clamped 16-byte vector of the array
+        v3_dma16(ssq_in + (size_t)v * 16, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ssql + (uint32_t)(wave - 2) * 1024u));
+    }
+
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- 4. steps
+    float acc = 0.f;                       // lanes kc == 0: row nl of the current row set (batch row 0 = D row 0, register 0)
+    uint32_t MAGIC = 0x64006400u, NEG1024 = 0xE400E400u;
+    asm volatile("" : "+v"(MAGIC), "+v"(NEG1024));
+    const u32x4 cfrag = {NEG1024, NEG1024, NEG1024, NEG1024};
+    const uint8_t* xa = xs + kc * 64;      // this lane's 32-k chunk of a step: four 16-byte slots
+    const bool per_channel = G.ngroups == 1;
+
+    struct StepOps {
+        v3h8 x[4];
+        uint32_t szw;
+    };
+    int c_rs = 0, c_i = 0;
+    auto fetch_ops = [&](StepOps& o) {
+        int s = wave + c_i * V3_NW;
+        s = s < G.nsteps ? s : G.nsteps - 1;
+        const v3h8* px = (const v3h8*)(xa + (size_t)s * 256);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o.x[w] = px[w];
+        o.szw = *(const uint32_t*)(szl + (size_t)c_rs * SZB + (size_t)(per_channel ? 0 : s) * 64 + nl * 4);
+    };
+    auto outlier_step = [&](int rs) {      // fp16 columns [K - 128, K): B fragments straight from the swizzled LDS rows
+        if (!OUTL) return;
+        if (wave != (G.nfull & (V3_NW - 1))) return;
+        const v3h8* px = (const v3h8*)(xa + (size_t)G.nfull * 256);
+        const uint8_t* prow = owl + rs * 4096 + nl * 256;
+        f32x4 P = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            P = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[jj], *(const v3h8*)(prow + (((kc * 4 + jj) ^ nl) & 15) * 16), P, 0, 0, 0);
+        acc += P[0];
+    };
+    auto flush = [&](int rs) {
+        if (kc == 0) red[(rs * V3_NW + wave) * 16 + nl] = acc;
+        acc = 0.f;
+    };
+    auto consume = [&](const u32x4& wv, const StepOps& cur, StepOps& nxt) {
+        if (c_i == 0) outlier_step(c_rs);
+        const int rs_now = c_rs;
+        const bool last_of_set = c_i + 1 >= nsw;
+        if (last_of_set) { c_i = 0; if (c_rs < RS - 1) ++c_rs; } else { ++c_i; }
+        fetch_ops(nxt);                    // LDS reads of the NEXT step go out before this one's math
+        // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
+        u32x4 bf[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t v = wv[w], t = v >> 8;
+            bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
+            bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q
+            bf[2][w] = (t & 0x000f000fu) | MAGIC;
+            bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+        }
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const v3h8 c8 = __builtin_bit_cast(v3h8, cfrag);
+        f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
+        f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
+        f32x4 Alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[0], c8, z4, 0, 0, 0);
+        f32x4 Ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[1], c8, z4, 0, 0, 0);
+        Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
+        Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
+        Alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[2], c8, Alo, 0, 0, 0);
+        Ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[3], c8, Ahi, 0, 0, 0);
+        const h2 szw = as_h2(cur.szw);
+        const float sf = (float)szw[0], zf = (float)szw[1];
+        const float t = (Plo[0] + Alo[0]) + 0.0625f * (Phi[0] + Ahi[0]);
+        acc += sf * t + zf * ((Alo[0] + Ahi[0]) * -0.0009765625f);
+        if (last_of_set) flush(rs_now);
+    };
+
+    if (nsw == 0) {        // K - n_out < 128 * (wave + 1): this wave has no INT4 step, possibly the outlier step
+        for (int rs = 0; rs < RS; ++rs) {
+            outlier_step(rs);
+            flush(rs);
+        }
+    } else {
+        const int total = RS * nsw;
+        const int nrounds = (total + D - 1) / D;
+        StepOps opA, opB;
+        fetch_ops(opA);
+        for (int rd = 0; rd + 1 < nrounds; ++rd) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (d & 1) consume(ring[d], opB, opA);
+                else consume(ring[d], opA, opB);
+                issue(ring[d]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if ((nrounds - 1) * D + d < total) {
+                if (d & 1) consume(ring[d], opB, opA);
+                else consume(ring[d], opA, opB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- 5. combine the waves, finish the norm, fused epilogues
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // step 2b's pieces (a wave without ring steps never waited)
+    __syncthreads();
+    float rs_norm = 1.f;
+    if (ssq_in) {               // every wave sums the (<= 512) partials itself, in a fixed order: no second barrier
+        float s = (lane < ssq_n ? ssql[lane] : 0.f);
+#pragma unroll
+        for (int i = 1; i < V3_MAX_SSQ / 64; ++i) s += (lane + 64 * i < ssq_n ? ssql[lane + 64 * i] : 0.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        rs_norm = rsqrtf(s / (float)G.K + eps);
+    }
+    auto row_sum = [&](int rs, int n) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < V3_NW; ++w) v += red[(rs * V3_NW + w) * 16 + n];
+        return v * rs_norm;
+    };
+    if (MODE == V3_MODE_PAIR) {
+        // set g: gate rows 0..7, up rows 8..15 of the same 8 outputs -> act = silu(gate) * up, rounded like the unfused
+        // sequence (gate and up to fp16 first, qeft_silu_mul arithmetic)
+        if (tid < RS * 8) {
+            const int rs = tid >> 3, n = tid & 7;
+            float gv = row_sum(rs, n), uv = row_sum(rs, n + 8);
+            if (bias) {
+                gv += (float)bias[(set0 + rs) * 16 + n];
+                uv += (float)bias[(set0 + rs) * 16 + 8 + n];
+            }
+            const f16 g16 = (f16)gv, u16 = (f16)uv;
+            yout[(set0 + rs) * 8 + n] = (f16)(silu_f32((float)g16) * (float)u16);
+        }
+        return;
+    }
+    float sq = 0.f;
+    if (tid < RS * 16) {
+        const int row = set0 * 16 + tid;
+        float v = row_sum(tid >> 4, tid & 15);
+        if (bias) v += (float)bias[row];
+        if (residual) {
+            v += ((const float*)epl)[tid];                          // lanes [0, 16) x 4 floats = the block's RS * 16 rows
+            y32[row] = v;
+            if (gamma_out) {
+                ynorm[row] = (f16)(v * (float)((const f16*)(epl + 256))[tid]);
+                sq = v * v;
+            }
+        } else {
+            yout[row] = (f16)v;
+        }
+    }
+    if (residual && gamma_out && wave == 0) {   // RS * 16 <= 64: the block's rows all sit in wave 0
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (lane == 0) ssq_out[blockIdx.x] = sq;
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace qeft

@@ -1,0 +1,107 @@
+// Launch logic of the v3 decode GEMV (gemv_v3.h) and the host-side enumerator of its address arithmetic.
+#include <cstdlib>
+
+#include "gemv_v3.h"
+
+namespace qeft {
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Blocks for `nsets` 16-row sets: one set per block while that leaves the 256 CUs two blocks each at most; wide launches
+// run 256 k long-lived blocks of ~3 sets (the ring then never drains between sets and the staging is paid once per
+// block).  QEFT_GEMV_BLOCKS overrides (lab).  Never more than V3_MAX_RS sets per block.
+int gemv_v3_blocks(int nsets) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("QEFT_GEMV_BLOCKS");
+        forced = e ? atoi(e) : 0;
+    }
+    int nblk;
+    if (forced > 0) nblk = nsets < forced ? nsets : forced;
+    else if (nsets < 512) nblk = nsets;
+    else {
+        int k = (nsets + 384) / 768;
+        if (k < 1) k = 1;
+        nblk = 256 * k;
+    }
+    if (ceil_div(nsets, nblk) > V3_MAX_RS) nblk = ceil_div(nsets, V3_MAX_RS);
+    return nblk;
+}
+
+// What the v3 kernel takes: whole 128-k steps, the checkpoint's r = 128 (or no outlier slice), group 128 or per-channel.
+bool gemv_v3_ok(int K, int G, int n_out) { return K % 128 == 0 && K >= 128 && (n_out == 0 || (n_out == 128 && K > 128)) && (G == 128 || G == K); }
+
+template <int D, bool OUTL>
+static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
+    auto go = [&](auto kern) -> hipError_t {
+        if (smem > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(V3_NW * 64), smem, st, a);
+        return hipGetLastError();
+    };
+    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<D, OUTL, V3_MODE_PAIR>) : go(gemv_v3_kernel<D, OUTL, V3_MODE_PLAIN>);
+}
+
+hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
+    const int nblk = gemv_v3_blocks(a.g.nsets);
+    a.rs_cap = ceil_div(a.g.nsets, nblk);
+    a.nblk = nblk;
+    a.sets_q = a.g.nsets / nblk;
+    a.sets_r = a.g.nsets % nblk;
+    const size_t smem = v3_smem_bytes(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap);
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    static const char* denv = getenv("QEFT_GEMV_DEPTH");     // lab: force the ring depth (4 or 6)
+    const int depth = denv ? (atoi(denv) == 6 ? 6 : 4) : (a.g.K > 6144 ? 6 : 4);
+    g_last_variant = mode == V3_MODE_PAIR ? "gemv_v3_pair" : "gemv_v3";
+    if (a.g.n_out > 0) return depth == 6 ? launch_dm<6, true>(a, mode, nblk, smem, st) : launch_dm<4, true>(a, mode, nblk, smem, st);
+    return depth == 6 ? launch_dm<6, false>(a, mode, nblk, smem, st) : launch_dm<4, false>(a, mode, nblk, smem, st);
+}
+
+// ---- host-side enumeration of every address the kernel can form for a configuration (no GPU involved).
+// Walks all blocks x waves x lanes x {staging pieces, ring issues incl. the clamped ones past the end, epilogue operands,
+// output rows} with the SAME __host__ __device__ functions the kernel uses and counts accesses that leave their operand.
+// n_rows_have: the number of rows the operands really hold (== G.nsets * 16 unless the caller is the negative control).
+long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in) {
+    long long bad = 0;
+    const size_t qw_bytes = (size_t)(n_rows_have / 4) * G.K * 2, sz_bytes = (size_t)(n_rows_have / 16) * G.ngroups * 64,
+                 ow_bytes = (size_t)n_rows_have * 128 * 2, res_bytes = (size_t)n_rows_have * 4, gam_bytes = (size_t)n_rows_have * 2;
+    const int nblk = gemv_v3_blocks(G.nsets);
+    const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups);
+    for (int b = 0; b < nblk; ++b) {
+        int set0, RS;
+        v3_block_sets(v3_xcd_block(b, nblk), G.nsets / nblk, G.nsets % nblk, set0, RS);
+        if (RS < 1 || RS > V3_MAX_RS || set0 < 0 || set0 + RS > G.nsets) { ++bad; continue; }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int nl = lane & 15, kc = lane >> 4;
+            for (int p = 0; p < (XB >> 10); ++p) bad += (size_t)v3_x_off(G, p, lane) + 16 > (size_t)G.K * 2;
+            bad += v3_epi_off(set0, RS, lane) + 16 > (lane < 16 ? res_bytes : gam_bytes);
+            if (n_ssq_in > 0)
+                for (int w = 2; w < 4; ++w)
+                    if ((w - 2) * 256 < n_ssq_in) {
+                        int v = (w - 2) * 64 + lane;
+                        if (v > ((n_ssq_in - 1) >> 2)) v = (n_ssq_in - 1) >> 2;
+                        bad += (size_t)v * 16 + 16 > (size_t)((n_ssq_in + 3) / 4 * 4) * 4;     // the array is padded to 4 floats
+                    }
+            for (int rs = 0; rs < RS; ++rs) {
+                for (int j = 0; j < (SZB >> 10); ++j) bad += v3_sz_off(G, set0 + rs, j, lane) + 16 > sz_bytes;
+                if (G.n_out > 0)
+                    for (int j = 0; j < 4; ++j) bad += v3_ow_off(set0 + rs, j, lane) + 16 > ow_bytes;
+                if (kc == 0) bad += (set0 + rs) * 16 + nl >= n_rows_have;
+            }
+            for (int wave = 0; wave < V3_NW; ++wave) {
+                const int nsw = (G.nfull - wave + V3_NW - 1) / V3_NW;
+                for (int rs = 0; rs < RS; ++rs)
+                    for (int i = 0; i < (nsw > 0 ? nsw : 1); ++i) {
+                        uint32_t so = (uint32_t)(wave + i * V3_NW) * 256u;
+                        if (so > v3_last_step_off(G)) so = v3_last_step_off(G);
+                        bad += v3_w_set_off(G, set0) + (size_t)rs * G.K * 8 + so + v3_w_lane_off(G, nl, kc) + 16 > qw_bytes;
+                    }
+            }
+        }
+    }
+    return bad;
+}
+
+}  // namespace qeft

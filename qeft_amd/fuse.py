@@ -1,0 +1,73 @@
+"""Derived operands of the v3 decode GEMV (csrc/gemv_v3.h), built once at load time and never saved.
+
+The kernel streams ONE packed operand per launch.  Two fusions of the decoder are therefore expressed in the data:
+
+* q|k|v (any linears that read the same x): their buffers concatenated along the output rows -- `concat_linears`.
+* gate|up with SiLU(gate) * up in the epilogue: rows pair-interleaved so that every 16-row MFMA set holds 8 gate rows and
+  the same 8 rows of up -- `pair_interleave`.  The checkpoint interleaves 4 rows per qweight row ("row group"), so this is
+  a permutation of whole qweight rows / 8-row halves of the scale shadow / whole oweight rows: no nibble is touched.
+
+The checkpoint buffers of the modules are left alone (state_dict round-trips unchanged).
+"""
+from types import SimpleNamespace
+
+import torch
+
+
+def _operand(qweight, sz_packed, oweight, bias, n, k, g, r):
+    return SimpleNamespace(qweight=qweight.contiguous(), sz_packed=sz_packed.contiguous(),
+                           oweight=oweight.contiguous() if oweight is not None else None,
+                           bias=bias.contiguous() if bias is not None else None,
+                           outfeatures=n, infeatures=k, group_size=g, outlierfeatures=r)
+
+
+def _plain_oweight(l):
+    ow = l.oweight.detach()
+    return (ow if ow.dtype == torch.float16 else ow.to(torch.float16))[:, -l.outlierfeatures:]
+
+
+def _szp(l):
+    szp = l._szp(l.scales) if hasattr(l, "_szp") else l.sz_packed
+    assert szp is not None, "the layer has no sz_packed shadow (group size 128 / per-channel on a GPU, N % 16 == 0)"
+    return szp
+
+
+def _check(layers):
+    l0 = layers[0]
+    for l in layers:
+        assert (l.infeatures, l.group_size, l.outlierfeatures) == (l0.infeatures, l0.group_size, l0.outlierfeatures)
+        assert l.outfeatures % 16 == 0
+        assert (l.bias is None) == (l0.bias is None)
+    return l0.infeatures, l0.group_size, l0.outlierfeatures
+
+
+def single(layer):
+    """One linear as a v3 operand (shares the module's buffers)."""
+    k, g, r = _check([layer])
+    return _operand(layer.qweight, _szp(layer), _plain_oweight(layer) if r else None, layer.bias, layer.outfeatures, k, g, r)
+
+
+def concat_linears(layers):
+    """q|k|v: rows of the linears one after the other (qweight [N/4, K], sz_packed [N/16, K/g, 16], oweight [N, r])."""
+    k, g, r = _check(layers)
+    return _operand(torch.cat([l.qweight for l in layers], 0), torch.cat([_szp(l) for l in layers], 0),
+                    torch.cat([_plain_oweight(l) for l in layers], 0) if r else None,
+                    torch.cat([l.bias for l in layers], 0) if layers[0].bias is not None else None,
+                    sum(l.outfeatures for l in layers), k, g, r)
+
+
+def pair_interleave(gate, up):
+    """gate|up: operand row 16 i + j = gate row 8 i + j (j < 8), up row 8 i + j - 8 (j >= 8); 2 N rows."""
+    k, g, r = _check([gate, up])
+    n = gate.outfeatures
+    assert up.outfeatures == n
+    qw = torch.cat([gate.qweight.view(n // 8, 2, -1), up.qweight.view(n // 8, 2, -1)], 1).reshape(n // 2, -1)
+    sg, su = _szp(gate), _szp(up)                       # [n/16, groups, 16]
+    ng = sg.shape[1]
+    halves = lambda s: s.view(n // 16, ng, 2, 8).permute(0, 2, 1, 3).reshape(n // 8, ng, 8)   # noqa: E731
+    szp = torch.cat([halves(sg), halves(su)], -1)       # [n/8, groups, 16]
+    ow = torch.cat([_plain_oweight(gate).view(n // 8, 8, r), _plain_oweight(up).view(n // 8, 8, r)], 1).reshape(2 * n, r) if r else None
+    bias = None
+    if gate.bias is not None:
+        bias = torch.cat([gate.bias.view(n // 8, 8), up.bias.view(n // 8, 8)], 1).reshape(2 * n)
+    return _operand(qw, szp, ow, bias, 2 * n, k, g, r)

@@ -328,6 +328,19 @@ class DecodeEngine:
         self.greedy = False
         self.graph = None
         self.use_graph = use_graph
+        # v3 path (single GPU, 4 bits, the shapes gemv_v3.h takes): raw-x GEMVs with the norms / SiLU on the producers'
+        # epilogues and an fp32 residual stream.  QEFT_ENGINE_V2=1 keeps the round-1 launch sequence (A/B timing).
+        g_, k_ok = s.group_size, (s.hidden % 128 == 0 and s.inter % 128 == 0)
+        self.v3 = (self.bits == 4 and not tp and k_ok and s.n_out in (0, 128) and g_ == 128 and s.hidden % 16 == 0
+                   and s.inter % 16 == 0 and kvd % 16 == 0 and os.environ.get("QEFT_ENGINE_V2") != "1")
+        if self.v3:
+            self.h32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)
+            self.n_ssq_tb = self.lib.qeft_token_begin_norm_blocks(s.hidden)
+            self.n_ssq_lin = self.lib.qeft_decode_linear_blocks(s.hidden)
+            self.ssq = torch.zeros((max(self.n_ssq_tb, self.n_ssq_lin) + 3) // 4 * 4, dtype=torch.float32, device=dev)
+            self.qkv_out = torch.zeros(s.hidden + 2 * kvd, **f16)      # q | k | v of one launch; self.q / k / v are views
+            self.q, self.k, self.v = self.qkv_out[:s.hidden], self.qkv_out[s.hidden:s.hidden + kvd], self.qkv_out[s.hidden + kvd:]
+            self.v3ops = []
         # per-layer local linears + argument packs (host arrays of device pointers must stay alive)
         self.lin = []
         self.packs = []
@@ -348,6 +361,11 @@ class DecodeEngine:
             qkv = [names["q"], names["k"], names["v"]]
             gu = [names["g"], names["u"]]
             no = s.n_out
+            if self.v3:
+                # derived operands (qeft_amd/fuse.py): q|k|v concatenated, gate|up pair-interleaved for the SiLU epilogue
+                from . import fuse
+                self.v3ops.append(dict(qkv=fuse.concat_linears(qkv), o=fuse.single(names["o"]),
+                                       gu=fuse.pair_interleave(*gu), d=fuse.single(names["d"])))
             if tp:
                 qkv_y = [self.qkv_loc[:self.hs], self.qkv_loc[self.hs:self.hs + self.kvs], self.qkv_loc[self.hs + self.kvs:]]
             else:
@@ -395,6 +413,8 @@ class DecodeEngine:
         """The kernel(s) behind the quantized linears of a token (for bench.py's roofline record)."""
         if self.bits == 3:
             return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel <BITS = 3>"
+        if self.v3:
+            return "qeft::gemv_v3_kernel"
         return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel"
 
     def weight_bytes_per_token(self):
@@ -411,6 +431,8 @@ class DecodeEngine:
     def _launch_token(self, linears_only=False, only=None):
         """only (with linears_only): launch just one GEMV of every layer -- "qkv", "o", "gu" or "d" -- for per-kernel timing."""
         import torch.distributed as dist
+        if self.v3:
+            return self._launch_token_v3(linears_only, only)
         s, lib, ck, P, tp = self.m.shape, self.lib, _lib.check, self.P, self.tp
         w3 = self.bits == 3
         gemv_group = lib.qeft_gemv_w3_group if w3 else lib.qeft_gemv_w4_group
@@ -510,6 +532,53 @@ class DecodeEngine:
         # an even number of buffer swaps per token: the result is back in hbuf[0]
         ck(lib.qeft_rmsnorm(h.data_ptr(), None, self.m.model.norm.data_ptr(), None, self.hn.data_ptr(), 1,
                             s.hidden, s.rms_eps, st))
+        torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
+        ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
+                              1 if self.greedy else 0, st))
+
+    @torch.no_grad()
+    def _launch_token_v3(self, linears_only=False, only=None):
+        """One token on the v3 GEMV (gemv_v3.h): every quantized linear reads its fp16 input vector as it is; the RMSNorms
+        are split into (h * gamma, partial sums of h^2) on the producer's epilogue and a deferred 1/rms on the consumer's;
+        SiLU(gate) * up is formed in the gate|up launch; the residual stream h32 stays fp32."""
+        s, lib, ck = self.m.shape, self.lib, _lib.check
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        g, no, eps = s.group_size, s.n_out, s.rms_eps
+        layers = self.m.model.layers
+        xn, ssq, h32 = self.xn.data_ptr(), self.ssq.data_ptr(), self.h32.data_ptr()
+
+        def lin(op, x, y, mode=0, residual=None, ssq_in=None, n_ssq=0, gamma_out=None):
+            return lib.qeft_decode_linear(x, op.qweight.data_ptr(), op.sz_packed.data_ptr(),
+                                          op.oweight.data_ptr() if no else None, None, y, op.outfeatures, op.infeatures, g, no,
+                                          mode, residual, ssq_in, n_ssq, eps, gamma_out, xn if gamma_out else None,
+                                          ssq if gamma_out else None, st)
+
+        def pick(tag):
+            return lin if only in (None, tag) else (lambda *a, **kw: 0)
+        if not linears_only:
+            ck(lib.qeft_token_begin_norm(self.m.model.embed_tokens.weight.data_ptr(), self.tok.data_ptr(),
+                                         self.rope_tab.data_ptr(), self.pos.data_ptr(), h32, self.rope_row.data_ptr(),
+                                         layers[0].input_layernorm.data_ptr(), xn, ssq, s.hidden, s.vocab, s.max_seq, st))
+        n_ssq = self.n_ssq_tb
+        for li, L in enumerate(layers):
+            pk = self.v3ops[li]
+            ck(pick("qkv")(pk["qkv"], xn, self.qkv_out.data_ptr(), ssq_in=ssq, n_ssq=n_ssq))
+            if not linears_only:
+                ck(lib.qeft_rope_attn_decode(self.q.data_ptr(), self.k.data_ptr(), self.v.data_ptr(),
+                                             self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
+                                             self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                             self.att_pos[li].data_ptr() if self.att_pos[li] is not None else None,
+                                             self.att.data_ptr(),
+                                             self.attn_ws.data_ptr() if self.attn_ws is not None else None,
+                                             self.attn_split, s.n_heads, s.n_kv_heads, s.max_seq, st))
+            ck(pick("o")(pk["o"], self.att.data_ptr(), h32, residual=h32, gamma_out=L.post_attention_layernorm.data_ptr()))
+            n_ssq = self.n_ssq_lin
+            ck(pick("gu")(pk["gu"], xn, self.act.data_ptr(), mode=1, ssq_in=ssq, n_ssq=n_ssq))
+            nxt = layers[li + 1].input_layernorm.data_ptr() if li + 1 < len(layers) else None
+            ck(pick("d")(pk["d"], self.act.data_ptr(), h32, residual=h32, gamma_out=nxt))
+        if linears_only:
+            return
+        ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, eps, st))
         torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
         ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
                               1 if self.greedy else 0, st))

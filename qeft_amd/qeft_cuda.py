@@ -324,3 +324,67 @@ def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_
                 q[b].data_ptr(), k[b].data_ptr(), v[b].data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), L,
                 k_cache[b].data_ptr(), v_cache[b].data_ptr(), pos.data_ptr() + 4 * b, out[b].data_ptr(), H, Hkv, L, st))
     return out
+
+
+# ---- v3 decode linear (include/qeft_hip.h, "v3 decode linear"): batch-1 GEMV with producer-side epilogues ----------------
+V3_PLAIN, V3_PAIR = 0, 1
+
+
+def decode_linear_blocks(n_rows):
+    """Number of partial sums (= blocks) a decode_linear launch over n_rows operand rows writes to ssq_out."""
+    return _lib.lib().qeft_decode_linear_blocks(n_rows)
+
+
+def decode_linear(x, op, mode=V3_PLAIN, residual=None, ssq_in=None, eps=0.0, gamma_out=None, out=None):
+    """y = Wdeq . x for one packed operand and the fp16 vector x[K], one launch of the v3 GEMV (qeft_decode_linear).
+
+    op: an object with qweight / sz_packed / oweight (plain fp16 [n, r]) / bias / outfeatures / infeatures / group_size /
+        outlierfeatures -- a QuantLinear after set_kernel(), or a derived operand from qeft_amd.fuse (q|k|v concatenated,
+        gate|up pair-interleaved).
+    mode V3_PAIR: op is fuse.pair_interleave(gate, up) -> returns silu(gate) * up (fp16 [n/2]).
+    residual (fp32 [n]): returns y32 = Wx + residual (fp32; `out` may alias residual for an in-place update).
+    ssq_in (fp32 partial sums): x is (v * gamma) and ssq_in the partial sums of v^2: y is scaled by rsqrt(sum / K + eps).
+    gamma_out (fp16 [n], with residual): also returns (y_norm = fp16(y * gamma_out), ssq partials of y) for the next launch.
+    Returns y, or (y, y_norm, ssq) with gamma_out."""
+    n, k, g, r = op.outfeatures, op.infeatures, op.group_size, op.outlierfeatures
+    _need(x.is_cuda and x.dtype == torch.float16 and x.numel() == k and x.is_contiguous(), "x must be a contiguous Half [K] GPU tensor")
+    szp = getattr(op, "sz_packed", None)
+    _need(szp is not None, "decode_linear needs the sz_packed buffer (QuantLinear.set_kernel on a GPU)")
+    dev = x.device
+    ow = None
+    if r:
+        ow = op.oweight if op.oweight.dtype == torch.float16 else op.oweight.to(torch.float16)
+        _need(ow.is_contiguous() and tuple(ow.shape) == (n, r), "oweight must be a contiguous [n, r] tensor")
+    if residual is not None:
+        _need(mode == V3_PLAIN and residual.dtype == torch.float32 and residual.numel() == n, "residual must be Float [n]")
+        y = out if out is not None else torch.empty(n, dtype=torch.float32, device=dev)
+    else:
+        y = out if out is not None else torch.empty(n // 2 if mode == V3_PAIR else n, dtype=torch.float16, device=dev)
+    y_norm = ssq = None
+    if gamma_out is not None:
+        y_norm = torch.empty(n, dtype=torch.float16, device=dev)
+        ssq = torch.zeros((decode_linear_blocks(n) + 3) // 4 * 4, dtype=torch.float32, device=dev)[:decode_linear_blocks(n)]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().qeft_decode_linear(
+            x.data_ptr(), op.qweight.data_ptr(), szp.data_ptr(), ow.data_ptr() if r else None,
+            op.bias.data_ptr() if op.bias is not None else None, y.data_ptr(), n, k, g, r, mode,
+            residual.data_ptr() if residual is not None else None,
+            ssq_in.data_ptr() if ssq_in is not None else None, ssq_in.numel() if ssq_in is not None else 0, float(eps),
+            gamma_out.data_ptr() if gamma_out is not None else None,
+            y_norm.data_ptr() if y_norm is not None else None, ssq.data_ptr() if ssq is not None else None, _stream(x)))
+    return (y, y_norm, ssq) if gamma_out is not None else y
+
+
+def residual_norm(h32, add=None, gamma=None, out=None):
+    """h_out (fp32) = h32 (+ add fp16); with gamma also (fp16(h_out * gamma), partial sums of h_out^2) (qeft_residual_norm)."""
+    n = h32.numel()
+    h_out = out if out is not None else torch.empty_like(h32)
+    hn = torch.empty(n, dtype=torch.float16, device=h32.device) if gamma is not None else None
+    nb = _lib.lib().qeft_token_begin_norm_blocks(n)
+    ssq = torch.zeros((nb + 3) // 4 * 4, dtype=torch.float32, device=h32.device)[:nb] if gamma is not None else None
+    with torch.cuda.device(h32.device):
+        _lib.check(_lib.lib().qeft_residual_norm(h32.data_ptr(), add.data_ptr() if add is not None else None,
+                                                 gamma.data_ptr() if gamma is not None else None, h_out.data_ptr(),
+                                                 hn.data_ptr() if hn is not None else None,
+                                                 ssq.data_ptr() if ssq is not None else None, n, _stream(h32)))
+    return (h_out, hn, ssq) if gamma is not None else h_out

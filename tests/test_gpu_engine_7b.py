@@ -27,6 +27,7 @@ def _compare(got, ref, tokens):
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item() / scale
     dn = abs(nll_from_logits(got, tokens) - nll_from_logits(ref, tokens))
+    print(f"[7b parity] T={tokens.numel()} max|dlogit|/max|logit|={err:.3e} |dNLL|={dn:.3e}")
     assert err < LOGIT_TOL, err
     assert dn <= NLL_TOL, dn
     # the argmax sequence agrees wherever the dense model's top-2 margin exceeds the logit tolerance
