@@ -36,7 +36,8 @@
 
 namespace qeft {
 
-constexpr int V3_NW = 8;        // waves per block; wave w owns the 128-k steps w, w + 8, ... of each of its row sets
+constexpr int V3_NW = 8;        // waves per block (the kernel is also instantiated with 16); wave w owns the 128-k steps w, w + NW, ...
+constexpr int V3_NW_MAX = 16;
 constexpr int V3_MAX_RS = 4;    // 16-row sets per block (LDS is carved for rs_cap <= 4)
 constexpr int V3_MAX_SSQ = 512; // partial sums of squares a consumer accepts
 constexpr int V3_MODE_PLAIN = 0;
@@ -71,7 +72,7 @@ __host__ __device__ constexpr int v3_x_bytes(int K) { return (K * 2 + 1023) / 10
 __host__ __device__ constexpr int v3_sz_bytes(int ngroups) { return (ngroups * 64 + 1023) / 1024 * 1024; }   // per row set
 __host__ __device__ constexpr size_t v3_smem_bytes(int K, int ngroups, int n_out, int rs_cap) {
     return (size_t)v3_x_bytes(K) + (size_t)rs_cap * v3_sz_bytes(ngroups) + (n_out > 0 ? (size_t)rs_cap * 4096 : 0) +
-           1024 /* epilogue operands */ + 2048 /* ssq_in */ + (size_t)rs_cap * V3_NW * 16 * 4 + 64;
+           1024 /* epilogue operands */ + 2048 /* ssq_in */ + (size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64;
 }
 
 // ---- source byte offsets of every load (relative to the operand's base)
@@ -127,8 +128,10 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int D, bool OUTL, int MODE>
-__global__ __launch_bounds__(V3_NW * 64) void gemv_v3_kernel(V3Args a) {
+// NW waves per block (8, or 16 for launches of one block per CU: twice the instruction streams per SIMD for the same bytes);
+// wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
+template <int NW, int D, bool OUTL, int MODE, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
     static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
     // every argument the prologue needs is copied to registers here, in one batch of scalar loads behind ONE wait: argument
     // loads that hipcc leaves next to their first use each cost a dependent scalar-memory round trip
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(V3_NW * 64) void gemv_v3_kernel(V3Args a) {
     uint8_t* owl = szl + rs_cap * SZB;                                // [rs_cap][16 rows][16 chunks ^ row][8] fp16
     uint8_t* epl = owl + (OUTL ? rs_cap * 4096 : 0);                  // [64 lanes][16 B]: residual | gamma_out of the block's rows
     float* ssql = (float*)(epl + 1024);                               // [512] ssq_in
-    float* red = ssql + V3_MAX_SSQ;                                   // [rs_cap][8 waves][16]
+    float* red = ssql + V3_MAX_SSQ;                                   // [rs_cap][NW][16]
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -167,34 +170,40 @@ __global__ __launch_bounds__(V3_NW * 64) void gemv_v3_kernel(V3Args a) {
     int set0, RS;
     v3_block_sets(v3_xcd_block(blockIdx.x, nblk), sets_q, sets_r, set0, RS);
 
-    // ---- 1. staging by LDS-DMA.  x: waves 0..7 take pieces w, w + 8, ..; per row set the scale words (piece j = wave) and
-    //         the outlier rows (waves 4..7, piece wave - 4).  No VGPR destination, no VALU on the data, nothing to wait for
-    //         until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
+    // ---- 1. staging by LDS-DMA.  x: the waves take pieces w, w + NW, ..; per row set the scale words (piece j = wave) and
+    //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
+    //         wait for until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
     const int PX = XB >> 10, SPS = SZB >> 10;
-    for (int p = wave; p < PX; p += V3_NW)
+    for (int p = wave; p < PX; p += NW)
         v3_dma16(xptr + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 10)));
     for (int rs = 0; rs < RS; ++rs) {
-        for (int j = wave; j < SPS; j += V3_NW)
+        for (int j = wave; j < SPS; j += NW)
             v3_dma16(szp + v3_sz_off(G, set0 + rs, j, lane),
                      __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)XB + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
-        if (OUTL && wave >= 4)
-            v3_dma16(ow + v3_ow_off(set0 + rs, wave - 4, lane),
-                     __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - 4) << 10)));
+        if (OUTL && wave >= NW - 4)
+            v3_dma16(ow + v3_ow_off(set0 + rs, wave - (NW - 4), lane),
+                     __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - (NW - 4)) << 10)));
     }
 
-    // ---- 2. weight stream: ring of D steps per wave, branch-free, oldest first.  The wave's work is the sequence
-    //         t = 0 .. RS*nsw-1 of (row set t / nsw, step wave + 8 (t % nsw)); issues past the end re-read a valid address.
-    const int nsw = (G.nfull - wave + V3_NW - 1) / V3_NW;
-    const uint32_t last_off = v3_last_step_off(G);
+    // ---- 2. weight stream: ring of D loads per wave, branch-free, oldest first.  The wave's work is the sequence
+    //         t = 0 .. nsw*RS-1 of (step wave + NW (t / RS), row set t % RS): STEP-major, so the x fragments and the bias
+    //         sums of a step are fetched / computed once and serve all RS row sets.  Issues past the end re-read a valid address.
+    const int nsw = (G.nfull - wave + NW - 1) / NW;
+    const uint32_t set_bytes = (uint32_t)G.K * 8u;                   // one 16-row set = 4 row groups of 2 K bytes
     const uint8_t* const wbase = qw + v3_w_set_off(G, set0);         // wave-uniform
     const uint32_t lane_off = v3_w_lane_off(G, nl, kc);
-    const uint32_t set_bytes = (uint32_t)G.K * 8u;                   // one 16-row set = 4 row groups of 2 K bytes
+    const uint32_t step0 = min((uint32_t)wave * 256u, v3_last_step_off(G));
     u32x4 ring[D];
     int p_rs = 0, p_i = 0;
+    uint32_t p_off = step0;                                          // uniform byte offset of the next issue
     auto issue = [&](u32x4& b) {
-        const uint8_t* sp = wbase + ((size_t)p_rs * set_bytes + min((uint32_t)(wave + p_i * V3_NW) * 256u, last_off));   // uniform
-        b = __builtin_nontemporal_load((const u32x4*)(sp + lane_off));
-        if (++p_i >= nsw) { p_i = 0; if (p_rs < RS - 1) ++p_rs; }
+        b = __builtin_nontemporal_load((const u32x4*)(wbase + p_off + lane_off));
+        p_off += set_bytes;
+        if (++p_rs >= RS) {                                          // next step (or, past the end, the last one again)
+            p_rs = 0;
+            if (p_i + 1 < nsw) ++p_i;
+            p_off = step0 + (uint32_t)p_i * (NW * 256u);
+        }
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -216,106 +225,128 @@ __global__ __launch_bounds__(V3_NW * 64) void gemv_v3_kernel(V3Args a) {
         const int v = min((wave - 2) * 64 + lane, (ssq_n - 1) >> 2);             // clamped 16-byte vector of the array
         v3_dma16(ssq_in + (size_t)v * 16, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ssql + (uint32_t)(wave - 2) * 1024u));
     }
-
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // ---- 4. steps
-    float acc = 0.f;                       // lanes kc == 0: row nl of the current row set (batch row 0 = D row 0, register 0)
+    // ---- 4. steps.  acc[rs]: lanes kc == 0 hold row nl of row set rs (batch row 0 = D row 0, register 0)
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     uint32_t MAGIC = 0x64006400u, NEG1024 = 0xE400E400u;
     asm volatile("" : "+v"(MAGIC), "+v"(NEG1024));
-    const u32x4 cfrag = {NEG1024, NEG1024, NEG1024, NEG1024};
+    const v3h8 c8 = __builtin_bit_cast(v3h8, u32x4{NEG1024, NEG1024, NEG1024, NEG1024});
     const uint8_t* xa = xs + kc * 64;      // this lane's 32-k chunk of a step: four 16-byte slots
     const bool per_channel = G.ngroups == 1;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
-    struct StepOps {
-        v3h8 x[4];
-        uint32_t szw;
-    };
-    int c_rs = 0, c_i = 0;
-    auto fetch_ops = [&](StepOps& o) {
-        int s = wave + c_i * V3_NW;
-        s = s < G.nsteps ? s : G.nsteps - 1;
-        const v3h8* px = (const v3h8*)(xa + (size_t)s * 256);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) o.x[w] = px[w];
-        o.szw = *(const uint32_t*)(szl + (size_t)c_rs * SZB + (size_t)(per_channel ? 0 : s) * 64 + nl * 4);
-    };
-    auto outlier_step = [&](int rs) {      // fp16 columns [K - 128, K): B fragments straight from the swizzled LDS rows
-        if (!OUTL) return;
-        if (wave != (G.nfull & (V3_NW - 1))) return;
+    // fp16 outlier columns [K - 128, K): one MFMA step per row set, B fragments from the swizzled LDS rows; the wave whose
+    // turn step `nfull` would be takes it, before its ring steps
+    if (OUTL && wave == (G.nfull & (NW - 1))) {
         const v3h8* px = (const v3h8*)(xa + (size_t)G.nfull * 256);
-        const uint8_t* prow = owl + rs * 4096 + nl * 256;
-        f32x4 P = {0.f, 0.f, 0.f, 0.f};
+        v3h8 xo[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-            P = __builtin_amdgcn_mfma_f32_16x16x32_f16(px[jj], *(const v3h8*)(prow + (((kc * 4 + jj) ^ nl) & 15) * 16), P, 0, 0, 0);
-        acc += P[0];
-    };
-    auto flush = [&](int rs) {
-        if (kc == 0) red[(rs * V3_NW + wave) * 16 + nl] = acc;
-        acc = 0.f;
-    };
-    auto consume = [&](const u32x4& wv, const StepOps& cur, StepOps& nxt) {
-        if (c_i == 0) outlier_step(c_rs);
-        const int rs_now = c_rs;
-        const bool last_of_set = c_i + 1 >= nsw;
-        if (last_of_set) { c_i = 0; if (c_rs < RS - 1) ++c_rs; } else { ++c_i; }
-        fetch_ops(nxt);                    // LDS reads of the NEXT step go out before this one's math
-        // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
-        u32x4 bf[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t v = wv[w], t = v >> 8;
-            bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
-            bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q
-            bf[2][w] = (t & 0x000f000fu) | MAGIC;
-            bf[3][w] = (t & 0x00f000f0u) | MAGIC;
-        }
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const v3h8 c8 = __builtin_bit_cast(v3h8, cfrag);
-        f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
-        f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
-        f32x4 Alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[0], c8, z4, 0, 0, 0);
-        f32x4 Ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[1], c8, z4, 0, 0, 0);
-        Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
-        Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
-        Alo = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[2], c8, Alo, 0, 0, 0);
-        Ahi = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.x[3], c8, Ahi, 0, 0, 0);
-        const h2 szw = as_h2(cur.szw);
-        const float sf = (float)szw[0], zf = (float)szw[1];
-        const float t = (Plo[0] + Alo[0]) + 0.0625f * (Phi[0] + Ahi[0]);
-        acc += sf * t + zf * ((Alo[0] + Ahi[0]) * -0.0009765625f);
-        if (last_of_set) flush(rs_now);
-    };
-
-    if (nsw == 0) {        // K - n_out < 128 * (wave + 1): this wave has no INT4 step, possibly the outlier step
+        for (int jj = 0; jj < 4; ++jj) xo[jj] = px[jj];
         for (int rs = 0; rs < RS; ++rs) {
-            outlier_step(rs);
-            flush(rs);
+            const uint8_t* prow = owl + rs * 4096 + nl * 256;
+            f32x4 P = z4;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                P = __builtin_amdgcn_mfma_f32_16x16x32_f16(xo[jj], *(const v3h8*)(prow + (((kc * 4 + jj) ^ nl) & 15) * 16), P, 0, 0, 0);
+            // (uniform 0 / 1 factors instead of an if-chain: hipcc turns a run-time choice among four scalars into a
+            //  scratch array, whose loads and stores would then sit in the vmcnt queue of the weight ring)
+            acc0 = fmaf(P[0], rs == 0 ? 1.f : 0.f, acc0);
+            acc1 = fmaf(P[0], rs == 1 ? 1.f : 0.f, acc1);
+            acc2 = fmaf(P[0], rs == 2 ? 1.f : 0.f, acc2);
+            acc3 = fmaf(P[0], rs == 3 ? 1.f : 0.f, acc3);
         }
-    } else {
+    }
+
+    if (nsw > 0) {
+        v3h8 xf[4], xn[4];                 // x fragments of the current / next step
+        float alo = 0.f, ahi = 0.f, ssum = 0.f;   // -1024 S_lo, -1024 S_hi, S of the current step (lanes kc == 0: batch row 0)
+        int c_rs = 0, c_i = 0;
+        auto load_x = [&](v3h8 (&o)[4], int i) {
+            const v3h8* px = (const v3h8*)(xa + (size_t)(wave + i * NW) * 256);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) o[w] = px[w];
+        };
+        auto scale_word = [&](int rs, int i) {
+            return *(const uint32_t*)(szl + (size_t)rs * SZB + (size_t)(per_channel ? 0 : wave + i * NW) * 64 + nl * 4);
+        };
+        load_x(xf, 0);
+        uint32_t szw = scale_word(0, 0), szw_n = 0;
+        auto consume = [&](const u32x4& wv) {
+            if (c_rs == 0) {               // first row set of a step: the step's bias sums (shared by its RS row sets)
+                if (!(ABL & 1)) {
+                    f32x4 A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], c8, z4, 0, 0, 0);
+                    f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], c8, z4, 0, 0, 0);
+                    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[2], c8, A0, 0, 0, 0);
+                    A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[3], c8, A1, 0, 0, 0);
+                    alo = A0[0];
+                    ahi = A1[0];
+                    ssum = (alo + ahi) * -0.0009765625f;
+                }
+                const int ni = c_i + 1 < nsw ? c_i + 1 : c_i;
+                load_x(xn, ni);            // next step's fragments: in flight during this step's RS row sets
+            }
+            // operands of the NEXT (step, row set): its scale word
+            const bool last_rs = c_rs + 1 >= RS;
+            const int n_rs = last_rs ? 0 : c_rs + 1, n_i = last_rs ? (c_i + 1 < nsw ? c_i + 1 : c_i) : c_i;
+            szw_n = scale_word(n_rs, n_i);
+            float add;
+            if (ABL & 4) {
+                add = __builtin_bit_cast(float, wv[0] ^ wv[1] ^ wv[2] ^ wv[3]);
+            } else {
+                // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
+                u32x4 bf[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t v = wv[w], t = v >> 8;
+                    bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
+                    bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q
+                    bf[2][w] = (t & 0x000f000fu) | MAGIC;
+                    bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+                }
+                f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
+                f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
+                Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
+                Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
+                const h2 sz2 = as_h2(szw);
+                add = (float)sz2[0] * ((Plo[0] + alo) + 0.0625f * (Phi[0] + ahi)) + (float)sz2[1] * ssum;
+            }
+            acc0 = fmaf(add, c_rs == 0 ? 1.f : 0.f, acc0);
+            acc1 = fmaf(add, c_rs == 1 ? 1.f : 0.f, acc1);
+            acc2 = fmaf(add, c_rs == 2 ? 1.f : 0.f, acc2);
+            acc3 = fmaf(add, c_rs == 3 ? 1.f : 0.f, acc3);
+            szw = szw_n;
+            if (last_rs) {
+                c_rs = 0;
+                ++c_i;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) xf[w] = xn[w];
+            } else {
+                ++c_rs;
+            }
+        };
         const int total = RS * nsw;
         const int nrounds = (total + D - 1) / D;
-        StepOps opA, opB;
-        fetch_ops(opA);
         for (int rd = 0; rd + 1 < nrounds; ++rd) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                if (d & 1) consume(ring[d], opB, opA);
-                else consume(ring[d], opA, opB);
+                consume(ring[d]);
                 issue(ring[d]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            if ((nrounds - 1) * D + d < total) {
-                if (d & 1) consume(ring[d], opB, opA);
-                else consume(ring[d], opA, opB);
-            }
+            if ((nrounds - 1) * D + d < total) consume(ring[d]);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (kc == 0) {
+        red[(0 * NW + wave) * 16 + nl] = acc0;
+        if (RS > 1) red[(1 * NW + wave) * 16 + nl] = acc1;
+        if (RS > 2) red[(2 * NW + wave) * 16 + nl] = acc2;
+        if (RS > 3) red[(3 * NW + wave) * 16 + nl] = acc3;
     }
 
     // ---- 5. combine the waves, finish the norm, fused epilogues
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(V3_NW * 64) void gemv_v3_kernel(V3Args a) {
     auto row_sum = [&](int rs, int n) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < V3_NW; ++w) v += red[(rs * V3_NW + w) * 16 + n];
+        for (int w = 0; w < NW; ++w) v += red[(rs * NW + w) * 16 + n];
         return v * rs_norm;
     };
     if (MODE == V3_MODE_PAIR) {

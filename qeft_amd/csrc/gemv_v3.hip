@@ -31,17 +31,31 @@ int gemv_v3_blocks(int nsets) {
 // What the v3 kernel takes: whole 128-k steps, the checkpoint's r = 128 (or no outlier slice), group 128 or per-channel.
 bool gemv_v3_ok(int K, int G, int n_out) { return K % 128 == 0 && K >= 128 && (n_out == 0 || (n_out == 128 && K > 128)) && (G == 128 || G == K); }
 
-template <int D, bool OUTL>
+template <int NW, int D, bool OUTL>
 static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
     auto go = [&](auto kern) -> hipError_t {
         if (smem > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(V3_NW * 64), smem, st, a);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, a);
         return hipGetLastError();
     };
-    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<D, OUTL, V3_MODE_PAIR>) : go(gemv_v3_kernel<D, OUTL, V3_MODE_PLAIN>);
+    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN>);
+}
+
+template <int NW, bool OUTL>
+static hipError_t launch_d(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
+    if (depth == 2) return launch_dm<NW, 2, OUTL>(a, mode, nblk, smem, st);
+    if constexpr (NW == 8) {            // 16-wave blocks are capped at 128 VGPRs: depth 6 would spill (and has too few steps)
+        if (depth == 6) return launch_dm<NW, 6, OUTL>(a, mode, nblk, smem, st);
+    }
+    return launch_dm<NW, 4, OUTL>(a, mode, nblk, smem, st);
+}
+
+static int env_int(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
 }
 
 hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
@@ -52,11 +66,14 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     a.sets_r = a.g.nsets % nblk;
     const size_t smem = v3_smem_bytes(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    static const char* denv = getenv("QEFT_GEMV_DEPTH");     // lab: force the ring depth (4 or 6)
-    const int depth = denv ? (atoi(denv) == 6 ? 6 : 4) : (a.g.K > 6144 ? 6 : 4);
+    // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
+    static const int f_nw = env_int("QEFT_GEMV_NW"), f_d = env_int("QEFT_GEMV_DEPTH");     // lab overrides
+    const int nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 ? 16 : 8);
+    const int steps_per_wave = ceil_div(a.g.nfull, nw) * a.rs_cap;
+    int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : (steps_per_wave <= 2 ? 2 : (a.g.K > 6144 && nw == 8 ? 6 : 4));
     g_last_variant = mode == V3_MODE_PAIR ? "gemv_v3_pair" : "gemv_v3";
-    if (a.g.n_out > 0) return depth == 6 ? launch_dm<6, true>(a, mode, nblk, smem, st) : launch_dm<4, true>(a, mode, nblk, smem, st);
-    return depth == 6 ? launch_dm<6, false>(a, mode, nblk, smem, st) : launch_dm<4, false>(a, mode, nblk, smem, st);
+    if (nw == 16) return a.g.n_out > 0 ? launch_d<16, true>(a, mode, nblk, smem, depth, st) : launch_d<16, false>(a, mode, nblk, smem, depth, st);
+    return a.g.n_out > 0 ? launch_d<8, true>(a, mode, nblk, smem, depth, st) : launch_d<8, false>(a, mode, nblk, smem, depth, st);
 }
 
 // ---- host-side enumeration of every address the kernel can form for a configuration (no GPU involved).
@@ -90,15 +107,16 @@ long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq
                     for (int j = 0; j < 4; ++j) bad += v3_ow_off(set0 + rs, j, lane) + 16 > ow_bytes;
                 if (kc == 0) bad += (set0 + rs) * 16 + nl >= n_rows_have;
             }
-            for (int wave = 0; wave < V3_NW; ++wave) {
-                const int nsw = (G.nfull - wave + V3_NW - 1) / V3_NW;
-                for (int rs = 0; rs < RS; ++rs)
-                    for (int i = 0; i < (nsw > 0 ? nsw : 1); ++i) {
-                        uint32_t so = (uint32_t)(wave + i * V3_NW) * 256u;
-                        if (so > v3_last_step_off(G)) so = v3_last_step_off(G);
-                        bad += v3_w_set_off(G, set0) + (size_t)rs * G.K * 8 + so + v3_w_lane_off(G, nl, kc) + 16 > qw_bytes;
-                    }
-            }
+            for (int NW = 8; NW <= 16; NW += 8)        // both instantiations of the kernel
+                for (int wave = 0; wave < NW; ++wave) {
+                    const int nsw = (G.nfull - wave + NW - 1) / NW;
+                    uint32_t step0 = (uint32_t)wave * 256u;
+                    if (step0 > v3_last_step_off(G)) step0 = v3_last_step_off(G);
+                    for (int rs = 0; rs < RS; ++rs)
+                        for (int i = 0; i < (nsw > 0 ? nsw : 1); ++i)
+                            bad += v3_w_set_off(G, set0) + (size_t)rs * G.K * 8 + step0 + (size_t)i * NW * 256 +
+                                   v3_w_lane_off(G, nl, kc) + 16 > qw_bytes;
+                }
         }
     }
     return bad;

@@ -1,0 +1,141 @@
+// Lab harness for the v3 decode GEMV (GPU box only): times kernel variants directly, cycling 12 weight sets per kind so that
+// nothing is served from L2 / MALL, on the four launch kinds of a Llama-2-7B decoder layer.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o gpurun_out/gemv_v3_lab
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "gemv_v3.h"
+
+namespace qeft { thread_local const char* g_last_variant = ""; }
+using namespace qeft;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void fill_random(uint32_t* p, size_t n, uint32_t seed, uint32_t andmask, uint32_t ormask) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = (uint32_t)i * 2654435761u ^ seed;
+    v ^= v >> 16; v *= 0x85ebca6bu; v ^= v >> 13; v *= 0xc2b2ae35u; v ^= v >> 16;
+    p[i] = (v & andmask) | ormask;
+}
+static void* dalloc(size_t bytes, uint32_t seed, uint32_t andmask = 0xffffffffu, uint32_t ormask = 0) {
+    void* p; CK(hipMalloc(&p, (bytes + 255) / 256 * 256));
+    size_t n = (bytes + 3) / 4;
+    hipLaunchKernelGGL(fill_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint32_t*)p, n, seed, andmask, ormask);
+    return p;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void stream_read(const u32x4* __restrict__ p, size_t vec_per_block, uint32_t* out) {
+    const u32x4* base = p + (size_t)blockIdx.x * vec_per_block;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = threadIdx.x; i < vec_per_block; i += 256 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (i + u * 256 < vec_per_block) ? __builtin_nontemporal_load(base + i + u * 256) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[threadIdx.x] = 1;
+}
+
+template <typename F>
+static float time_launches(int reps, int L, F f) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int l = 0; l < L; ++l) f(l);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) for (int l = 0; l < L; ++l) f(l);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / (reps * L);
+}
+
+struct Kind { const char* name; int n, k, mode; bool ssq, res; };
+struct Bufs { void *qw, *szp, *ow; };
+
+template <int NW, int D, int MODE, int ABL>
+static void launch(const V3Args& a, int nblk, size_t smem) {
+    auto kern = gemv_v3_kernel<NW, D, true, MODE, ABL>;
+    if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, a);
+}
+
+template <int NW, int D, int ABL>
+static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk) {
+    const int nsets = kd.n / 16;
+    if (nblk > nsets) nblk = nsets;
+    if ((nsets + nblk - 1) / nblk > V3_MAX_RS) { printf("    (skip: %d blocks need > %d sets per block)\n", nblk, V3_MAX_RS); return; }
+    V3Args a{};
+    a.x = (const f16*)x;
+    a.g = V3Geom{kd.k, 128, kd.k / 128, (kd.k - 128) / 128, kd.k / 128, nsets};
+    a.rs_cap = (nsets + nblk - 1) / nblk; a.nblk = nblk; a.sets_q = nsets / nblk; a.sets_r = nsets % nblk;
+    a.ssq_in = kd.ssq ? (const float*)ssq : nullptr; a.n_ssq_in = kd.ssq ? 256 : 0; a.eps = 1e-5f;
+    a.residual = kd.res ? (const float*)h32 : nullptr; a.y32 = kd.res ? (float*)h32 : nullptr;
+    a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
+    a.y = (f16*)y;
+    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap);
+    auto f = [&](int l) {
+        V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
+        if (kd.mode == V3_MODE_PAIR) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); else launch<NW, D, V3_MODE_PLAIN, ABL>(b, nblk, smem);
+    };
+    const double bytes = (double)kd.n * (kd.k - 128) / 2 + 2.0 * (kd.k / 128) * kd.n * 2 + (double)kd.n * 128 * 2 + 2 * kd.k + 2 * kd.n;
+    const float us = time_launches(20, (int)B.size(), f);
+    CK(hipGetLastError());
+    printf("  %-4s NW=%2d D=%d blocks=%4d ABL=%d : %7.2f us  %6.0f GB/s\n", kd.name, NW, D, nblk, ABL, us, bytes / us / 1e3);
+}
+
+int main() {
+    const int L = 12;
+    uint32_t* out; CK(hipMalloc(&out, 4096));
+    {   // streaming ceiling at the four launch sizes
+        size_t tot = (size_t)L * 56 * 1024 * 1024;
+        void* buf; CK(hipMalloc(&buf, tot)); CK(hipMemset(buf, 1, tot));
+        for (double mb : {9.3, 23.6, 27.8, 49.8}) {
+            size_t bytes = (size_t)(mb * 1024 * 1024) / 16384 * 16384;
+            for (int grid : {512, 1024}) {
+                size_t vpb = bytes / 16 / grid;
+                auto f8 = [&](int l) { hipLaunchKernelGGL(stream_read<8>, dim3(grid), dim3(256), 0, 0, (const u32x4*)((char*)buf + (size_t)l * 56 * 1024 * 1024), vpb, out); };
+                float u8 = time_launches(20, L, f8);
+                printf("stream %5.1f MiB grid %4d: %6.2f us %6.0f GB/s\n", mb, grid, u8, bytes / u8 / 1e3);
+            }
+        }
+        CK(hipFree(buf));
+    }
+    const Kind kinds[4] = {{"qkv", 12288, 4096, V3_MODE_PLAIN, true, false}, {"o", 4096, 4096, V3_MODE_PLAIN, false, true},
+                           {"gu", 22016, 4096, V3_MODE_PAIR, true, false}, {"d", 4096, 11008, V3_MODE_PLAIN, false, true}};
+    void* h32 = dalloc(4096 * 4, 1, 0x807fffffu, 0x3f000000u);
+    void* gam = dalloc(4096 * 2, 2, 0x03ff03ffu, 0x3c003c00u);
+    void* ssq = dalloc(2048 * 4, 3, 0x007fffffu, 0x3f800000u);
+    void* ynorm = dalloc(4096 * 2, 4);
+    for (const Kind& kd : kinds) {
+        std::vector<Bufs> B(L);
+        for (auto& b : B) {
+            b.qw = dalloc((size_t)kd.n * kd.k / 2, 17);
+            b.szp = dalloc((size_t)kd.n * (kd.k / 128) * 4, 3, 0x03ff03ffu, 0xa4001c00u);
+            b.ow = dalloc((size_t)kd.n * 128 * 2, 7, 0x83ff83ffu, 0x20002000u);
+        }
+        void* x = dalloc(kd.k * 2, 9, 0x83ff83ffu, 0x38003800u);
+        void* y = dalloc(kd.n * 2, 5);
+        printf("%s: n=%d k=%d\n", kd.name, kd.n, kd.k);
+        const int nsets = kd.n / 16;
+        for (int nblk : {256, 512, 768, 1024}) {
+            if (nblk > nsets) continue;
+            run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nblk);
+            run<16, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nblk);
+        }
+        const int nb = nsets < 512 ? nsets : 256 * ((nsets + 384) / 768);
+        run<8, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<16, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4, 1>(kd, B, x, y, h32, gam, ssq, ynorm, nb);     // no bias-sum MFMAs
+        run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);     // no math at all
+        run<16, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
+        (void)hipFree(x); (void)hipFree(y);
+    }
+    return 0;
+}
