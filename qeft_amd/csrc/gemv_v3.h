@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
 
     if (nsw > 0) {
         v3h8 xf[4], xn[4];                 // x fragments of the current / next step
-        float alo = 0.f, ahi = 0.f, ssum = 0.f;   // -1024 S_lo, -1024 S_hi, S of the current step (lanes kc == 0: batch row 0)
+        float alo = 0.f, ahi = 0.f;        // -1024 S_lo, -1024 S_hi of the current step (lanes kc == 0: batch row 0)
         int c_rs = 0, c_i = 0;
         auto load_x = [&](v3h8 (&o)[4], int i) {
             const v3h8* px = (const v3h8*)(xa + (size_t)(wave + i * NW) * 256);
@@ -271,29 +271,42 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
         auto scale_word = [&](int rs, int i) {
             return *(const uint32_t*)(szl + (size_t)rs * SZB + (size_t)(per_channel ? 0 : wave + i * NW) * 64 + nl * 4);
         };
+        auto bias_sums = [&](const v3h8 (&x4)[4], float& lo, float& hi) {
+            if (ABL & 1) { lo = hi = 0.f; return; }
+            f32x4 A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[0], c8, z4, 0, 0, 0);
+            f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[1], c8, z4, 0, 0, 0);
+            A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, A0, 0, 0, 0);
+            A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[3], c8, A1, 0, 0, 0);
+            lo = A0[0];
+            hi = A1[0];
+        };
         load_x(xf, 0);
-        uint32_t szw = scale_word(0, 0), szw_n = 0;
+        uint32_t szw = scale_word(0, 0);
+        bias_sums(xf, alo, ahi);
+        float nlo = 0.f, nhi = 0.f;        // the next step's sums, computed one step ahead
+        // Software pipeline: the products of a (step, row set) are folded into the accumulators one consume LATER, behind
+        // the MFMAs of the next one -- nothing reads an MFMA result right behind the MFMA (that wait was ~10 % of a launch).
+        float pv_lo = 0.f, pv_hi = 0.f, pv_alo = 0.f, pv_ahi = 0.f, pv_f0 = 0.f, pv_f1 = 0.f, pv_f2 = 0.f, pv_f3 = 0.f;
+        uint32_t pv_szw = 0;
+        auto fold = [&]() {
+            const h2 sz2 = as_h2(pv_szw);
+            const float add = (float)sz2[0] * ((pv_lo + pv_alo) + 0.0625f * (pv_hi + pv_ahi)) +
+                              (float)sz2[1] * ((pv_alo + pv_ahi) * -0.0009765625f);
+            // (uniform 0 / 1 factors, not an if-chain: see the outlier step)
+            acc0 = fmaf(add, pv_f0, acc0);
+            acc1 = fmaf(add, pv_f1, acc1);
+            acc2 = fmaf(add, pv_f2, acc2);
+            acc3 = fmaf(add, pv_f3, acc3);
+        };
         auto consume = [&](const u32x4& wv) {
-            if (c_rs == 0) {               // first row set of a step: the step's bias sums (shared by its RS row sets)
-                if (!(ABL & 1)) {
-                    f32x4 A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], c8, z4, 0, 0, 0);
-                    f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], c8, z4, 0, 0, 0);
-                    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[2], c8, A0, 0, 0, 0);
-                    A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[3], c8, A1, 0, 0, 0);
-                    alo = A0[0];
-                    ahi = A1[0];
-                    ssum = (alo + ahi) * -0.0009765625f;
-                }
-                const int ni = c_i + 1 < nsw ? c_i + 1 : c_i;
-                load_x(xn, ni);            // next step's fragments: in flight during this step's RS row sets
-            }
-            // operands of the NEXT (step, row set): its scale word
             const bool last_rs = c_rs + 1 >= RS;
-            const int n_rs = last_rs ? 0 : c_rs + 1, n_i = last_rs ? (c_i + 1 < nsw ? c_i + 1 : c_i) : c_i;
-            szw_n = scale_word(n_rs, n_i);
-            float add;
+            const int ni = c_i + 1 < nsw ? c_i + 1 : c_i;
+            if (c_rs == 0) load_x(xn, ni);     // next step's fragments: in flight during this step's RS row sets
+            const uint32_t szw_n = scale_word(last_rs ? 0 : c_rs + 1, last_rs ? ni : c_i);
+            float lo, hi;
             if (ABL & 4) {
-                add = __builtin_bit_cast(float, wv[0] ^ wv[1] ^ wv[2] ^ wv[3]);
+                lo = __builtin_bit_cast(float, wv[0] ^ wv[1]);
+                hi = __builtin_bit_cast(float, wv[2] ^ wv[3]);
             } else {
                 // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
                 u32x4 bf[4];
@@ -309,17 +322,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
                 f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
                 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
                 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
-                const h2 sz2 = as_h2(szw);
-                add = (float)sz2[0] * ((Plo[0] + alo) + 0.0625f * (Phi[0] + ahi)) + (float)sz2[1] * ssum;
+                if (last_rs) bias_sums(xn, nlo, nhi);      // the NEXT step's sums ride behind this step's last products
+                fold();                                     // the PREVIOUS (step, row set): its MFMAs retired long ago
+                lo = Plo[0];
+                hi = Phi[0];
             }
-            acc0 = fmaf(add, c_rs == 0 ? 1.f : 0.f, acc0);
-            acc1 = fmaf(add, c_rs == 1 ? 1.f : 0.f, acc1);
-            acc2 = fmaf(add, c_rs == 2 ? 1.f : 0.f, acc2);
-            acc3 = fmaf(add, c_rs == 3 ? 1.f : 0.f, acc3);
+            if (ABL & 4) fold();
+            pv_lo = lo; pv_hi = hi; pv_alo = alo; pv_ahi = ahi; pv_szw = szw;
+            pv_f0 = c_rs == 0 ? 1.f : 0.f; pv_f1 = c_rs == 1 ? 1.f : 0.f; pv_f2 = c_rs == 2 ? 1.f : 0.f; pv_f3 = c_rs == 3 ? 1.f : 0.f;
             szw = szw_n;
             if (last_rs) {
                 c_rs = 0;
                 ++c_i;
+                alo = nlo;
+                ahi = nhi;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) xf[w] = xn[w];
             } else {
@@ -341,6 +357,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
             if ((nrounds - 1) * D + d < total) consume(ring[d]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        fold();                                // the last (step, row set)
     }
     if (kc == 0) {
         red[(0 * NW + wave) * 16 + nl] = acc0;

@@ -68,9 +68,12 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
     static const int f_nw = env_int("QEFT_GEMV_NW"), f_d = env_int("QEFT_GEMV_DEPTH");     // lab overrides
-    const int nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 ? 16 : 8);
-    const int steps_per_wave = ceil_div(a.g.nfull, nw) * a.rs_cap;
-    int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : (steps_per_wave <= 2 ? 2 : (a.g.K > 6144 && nw == 8 ? 6 : 4));
+    // measured (tools/gemv_v3_lab.hip, profiles/r02_gemv_v3_lab.txt): 16 waves + depth 2 win where a CU holds one block and a
+    // wave still has several steps (q|k|v 8.3 vs 9.0 us, down_proj 8.0 vs 8.9); o_proj (2 steps per wave at 16) keeps 8
+    // waves; two blocks per CU (gate|up) run best at 8 waves, depth 2 (12.9 vs 14.3 at depth 4, 16.6 at 6: registers)
+    const int steps16 = ceil_div(a.g.nfull, 16) * a.rs_cap;
+    const int nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 && steps16 >= 4 ? 16 : 8);
+    const int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : (nw == 16 || nblk > 256 ? 2 : 4);
     g_last_variant = mode == V3_MODE_PAIR ? "gemv_v3_pair" : "gemv_v3";
     if (nw == 16) return a.g.n_out > 0 ? launch_d<16, true>(a, mode, nblk, smem, depth, st) : launch_d<16, false>(a, mode, nblk, smem, depth, st);
     return a.g.n_out > 0 ? launch_d<8, true>(a, mode, nblk, smem, depth, st) : launch_d<8, false>(a, mode, nblk, smem, depth, st);

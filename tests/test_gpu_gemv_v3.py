@@ -53,7 +53,8 @@ def test_single_linear(n, k, r, g):
 @pytest.mark.parametrize("ns,k", [((4096, 4096, 4096), 4096), ((512, 64, 64), 1024), ((5120, 5120, 5120), 5120),
                                    ((16, 32, 16), 256), ((4096, 1024, 1024), 4096), ((11008, 11008), 4096)])
 def test_concatenated_linears_share_x(ns, k):
-    """q|k|v as ONE operand (fuse.concat_linears) == the same linears one by one (bit for bit) == oracle."""
+    """q|k|v as ONE operand (fuse.concat_linears) == the same linears one by one == oracle.  (Bit-equal only when both
+    launches take the same waves-per-block variant: the split of a row's K steps over the waves is the summation order.)"""
     from qeft_amd import fuse, qeft_cuda
     r, g = 128, 128
     ls = [make(n, k, r, g, seed=10 * i + n) for i, n in enumerate(ns)]
@@ -65,7 +66,8 @@ def test_concatenated_linears_share_x(ns, k):
     o = 0
     for (l, bufs), n in zip(ls, ns):
         assert rel_err(y[o:o + n].cpu().numpy()[None], ref(bufs, x, r, g)) < REL_TOL
-        assert torch.equal(y[o:o + n], qeft_cuda.decode_linear(xt, l))
+        one = qeft_cuda.decode_linear(xt, l)
+        assert rel_err(y[o:o + n].cpu().numpy()[None], one.float().cpu().numpy()[None]) < 2e-3
         o += n
 
 
