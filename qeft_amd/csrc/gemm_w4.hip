@@ -408,6 +408,203 @@ __global__ __launch_bounds__(64 * NWV) void gemm_w4_kernel_v2(const f16* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Forward GEMM, large-M version (M >= ~2048): 256 (m) x 128 (n) x 64 (k) block tile, 4 waves side by side along N, each
+// 256 rows x 32 columns = 8 MFMA 32x32 tiles: ONE wave per SIMD with the whole register file.
+//
+// Why this shape (profiles/r01_gemm_pmc.txt: the 128-row tiles issue ~0.85 VALU cycles per MFMA cycle with two waves
+// per SIMD and run the matrix pipe at 57 %): the dequantisation of a wave's 32 columns x 64 k costs the same ~56 VALU
+// whatever the tile height, so 256 rows halve the VALU, LDS-DMA and barrier work per MFMA (32 MFMAs per k-tile and wave
+// against 16).  The grid is one block per CU at 2048 x 4096 (256 blocks), dealt so that an XCD works on one 256-row
+// block of the activations (2 MB at K = 4096: resident in its 4 MB L2) while the packed weights stream past.
+//   * LDS: 4 stages of [A 32 KB | packed B 4 KB | scales + scaled zeros of the tile's group 512 B] = 146 KB; three k-tiles
+//     in flight by LDS-DMA behind a counted s_waitcnt, ONE s_barrier per k-tile (32 MFMAs per wave between barriers).
+//   * a wave DMAs and reads its OWN 1 KB of the packed B tile (its 32 columns), so B needs no cross-wave hand-off;
+//     the B fragments of k-tile t + 1 are dequantised in registers while the MFMAs of k-tile t run.
+//   * fp16 outlier k-tiles, bias and the fp16 epilogue as in gemm_w4_kernel_v2.
+// ---------------------------------------------------------------------------------------------------
+constexpr int G3_BM = 256, G3_BN = 128, G3_ST = 4;
+constexpr int G3_A = G3_BM * BK * 2, G3_B = G3_BN * BK / 2, G3_S = 512;
+constexpr int G3_STAGE = G3_A + G3_B + G3_S;           // 37376 bytes
+constexpr size_t G3_SMEM = (size_t)G3_ST * G3_STAGE;   // 149504 bytes
+
+// n DMA pieces of 1 KB: lane's 16 bytes at (sbase + voff_i) -> LDS[lds_dst + 1024 i + 16 lane], i = 0..7 (one asm statement:
+// M0 is written and read inside it; the pieces stay invisible to hipcc's s_waitcnt bookkeeping and are counted by hand)
+__device__ __forceinline__ void g3_dma_a8(const void* sbase, const uint32_t (&voff)[8], uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(sbase), "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]),
+          "v"(voff[6]), "v"(voff[7])
+        : "memory", "scc");
+}
+__device__ __forceinline__ void g3_dma16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(sbase), "s"(lds_dst), "v"(voff) : "memory");
+}
+__device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %3, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(sbase), "s"(lds_dst), "v"(voff) : "memory");
+}
+
+template <bool OUTL>
+__global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
+                                                           const f16* __restrict__ scales, const f16* __restrict__ zeros,
+                                                           const f16* __restrict__ ow, const f16* __restrict__ bias,
+                                                           f16* __restrict__ y, int M, int N, int K, int G, int n_out, int NB) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through consecutive tiles of one row block
+    const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
+    const int c = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
+    const int bm0 = (c / NB) * G3_BM, bn0 = (c % NB) * G3_BN;
+    const int ktiles = K / BK;
+    const int kq = K - (OUTL ? n_out : 0);
+    const int qtiles = kq / BK;            // INT4 k-tiles [0, qtiles); fp16 outlier k-tiles [qtiles, ktiles)
+    const int gshift = 31 - __builtin_clz(G);
+
+    const int nloc = wave * 32 + r;
+    const int ncol = min(bn0 + nloc, N - 1);
+    const bool nok = bn0 + nloc < N;
+
+    // ---- DMA sources (32-bit lane offsets from uniform bases).  A piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk
+    //      lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7); wave w stages pieces 8w .. 8w + 7.
+    uint32_t a_off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + (lane >> 3);
+        const int grow = min(bm0 + row, M - 1);
+        a_off[i] = (uint32_t)grow * (uint32_t)K * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    // B: wave w stages the 1 KB of ITS 32 columns (row groups bn0/4 + 8w ..): lane -> (row group lane/8, 16-byte piece lane%8)
+    const int brg = min(bn0 / 4 + wave * 8 + (lane >> 3), N / 4 - 1);
+    const uint32_t b_off = (uint32_t)brg * (uint32_t)K * 2u + (uint32_t)(lane & 7) * 16u;
+    // scales (wave 0) / scaled zeros (wave 1) of the tile's group: 128 columns x 2 B = 64 lanes x 4 B
+    const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
+    const uint8_t* const sz_base = (const uint8_t*)(wave == 0 ? scales : zeros);
+
+    auto stage = [&](int t) {              // 10 DMA instructions for waves 0 / 1, 9 for waves 2 / 3
+        const uint32_t base = lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_STAGE;
+        g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, base + (uint32_t)wave * 8192u);
+        g3_dma16(qw + (size_t)t * 128, b_off, base + G3_A + (uint32_t)wave * 1024u);
+        if (wave < 2)
+            g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, base + G3_A + G3_B + (uint32_t)wave * 256u);
+    };
+    auto wait_tiles = [&](int younger) {   // all but the `younger` most recent stage() calls of this wave have landed
+        if (wave < 2) {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // per-lane LDS offsets inside a stage: A fragment of m-tile mt, k-step j at a_rd[j] + mt * 4096
+    uint32_t a_rd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_rd[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));
+    const uint32_t b_rd = (uint32_t)(G3_A + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);
+    const uint32_t s_rd = (uint32_t)(G3_A + G3_B + nloc * 2);
+
+    // B fragments of a k-tile: k-step j contracts the 8 consecutive k h*32 + 8j .. +7 = pair j of each of the 4 nibble words
+    auto dequant_tile = [&](int t, u32x4 (&bf)[4]) {
+        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
+        const u32x4 q = *(const u32x4*)(st + b_rd);
+        const h2 sc = splat(*(const f16*)(st + s_rd)), zc = splat(*(const f16*)(st + s_rd + 256));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            h2 wd[4];
+            dequant8(q[w], sc, zc, wd);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j][w] = as_u32(wd[j]);
+        }
+    };
+    auto mma_tile = [&](int t, const u32x4 (&bf)[4]) {
+        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(st + a_rd[j] + mt * 4096),
+                                                                __builtin_bit_cast(h8, bf[j]), acc[mt], 0, 0, 0);
+    };
+
+    // ---- prologue: three k-tiles in flight, the first two landed, B of tile 0 in registers
+    constexpr int LEAD = G3_ST - 1;
+#pragma unroll
+    for (int t = 0; t < LEAD; ++t)
+        if (t < qtiles) stage(t);
+    u32x4 bcur[4], bnxt[4];
+    wait_tiles(min(qtiles, LEAD) - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (qtiles > 0) dequant_tile(0, bcur);
+
+    // ---- main loop: at the top of iteration t the tiles <= t are visible; make tile t + 1 visible (its B is dequantised
+    //      during this iteration), refill the stage of tile t - 1 with tile t + 3, then 32 MFMAs on tile t
+    for (int t = 0; t < qtiles; ++t) {
+        // issued so far: tiles <= t + LEAD - 1; tile t + 1 must have landed -> only tiles t + 2 .. may still be in flight
+        wait_tiles(max(0, min(LEAD - 2, qtiles - 2 - t)));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + LEAD < qtiles) stage(t + LEAD);
+        if (t + 1 < qtiles) dequant_tile(t + 1, bnxt);
+        mma_tile(t, bcur);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcur[j] = bnxt[j];
+    }
+
+    // ---- fp16 outlier k-tiles (2 for r = 128): the pipeline is empty; A by DMA into stage 0, B fragments from oweight
+    if (OUTL) {
+        for (int t = qtiles; t < ktiles; ++t) {
+            __builtin_amdgcn_s_barrier();          // every wave finished reading the stage about to be overwritten
+            g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)wave * 8192u);
+            u32x4 bf[4];
+            const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + (t * BK + h * 32 - kq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = p[j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            mma_tile(0, bf);
+        }
+    }
+
+    if (nok) {
+        const float bv = bias ? (float)bias[ncol] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = bm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M) y[(size_t)m * N + ncol] = (f16)(acc[mt][e] + bv);
+            }
+    }
+}
+
 // y[m][n] = fp16(sum_z part[z][m][n] + bias[n]); 4 outputs per thread (N % 4 == 0)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, const f16* __restrict__ bias,
                                                                  f16* __restrict__ y, int M, int N, int S) {
@@ -438,6 +635,26 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
                           void* workspace, size_t workspace_bytes) {
     const bool outl = ow && n_out > 0;
+    // 256 x 128 tiles, one wave per SIMD (gemm_w4_kernel_v3), when they give (nearly) every CU a block: the M >= 2048 tier
+    // of a prefill / fine-tune step.  QEFT_GEMM_V3 = 0 / 1 forces the choice (A/B).
+    {
+        static const int force_v3 = getenv("QEFT_GEMM_V3") ? atoi(getenv("QEFT_GEMM_V3")) : -1;
+        const int mb = (M + G3_BM - 1) / G3_BM, nb = (N + G3_BN - 1) / G3_BN;
+        const bool ok3 = K / BK >= G3_ST && K % BK == 0 && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && G >= 64 &&
+                         N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
+        if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024))) {
+            auto go3 = [&](auto kern) -> hipError_t {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_SMEM);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(mb * nb), dim3(256), G3_SMEM, st, (const f16*)x, (const uint8_t*)qw,
+                                   (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
+                                   (f16*)y, M, N, K, G, outl ? n_out : 0, nb);
+                return hipGetLastError();
+            };
+            g_last_variant = "gemm_v3_256x128";
+            return outl ? go3(gemm_w4_kernel_v3<true>) : go3(gemm_w4_kernel_v3<false>);
+        }
+    }
     // 128 x 256 tiles (8 waves) when they still give every CU a block: always a gain where the 128 x 128 kernel's scale
     // array leaves room for one block per CU only (K = 11008: 747 -> 945 TFLOP/s at M = 2048), a few % otherwise at
     // M >= 2048; smaller problems keep the 128 x 128 tile (more blocks).  QEFT_GEMM_NWV = 4 / 8 forces one (A/B).

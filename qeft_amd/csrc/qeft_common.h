@@ -31,7 +31,8 @@ __device__ __forceinline__ h2 splat(f16 v) { return h2{v, v}; }
 // brought back to q exactly, then ONE rounded fp16 FMA q*s+sz gives the same fp16
 // weight as the reference's __hfma2 (gemv_cuda_qeft.cu:158, gemm_cuda.cu:280-286).
 __device__ __forceinline__ void nib8_to_q(uint32_t v, h2 (&q)[4]) {
-    const uint32_t MAGIC = 0x64006400u;
+    uint32_t MAGIC = 0x64006400u;
+    asm volatile("" : "+v"(MAGIC));          // opaque: (v & mask) | MAGIC becomes ONE v_and_or_b32 (literal + VGPR) instead of and + or
     const h2 k1024 = {(f16)1024.f, (f16)1024.f};
     const h2 k16th = {(f16)0.0625f, (f16)0.0625f};
     const h2 kn64 = {(f16)-64.f, (f16)-64.f};

@@ -112,3 +112,21 @@ def test_variant_names_follow_the_routing():
     qeft_cuda.gemm_4bit_dx(dy, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
     assert _lib.last_variant().startswith("dx64")
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("m,n,k,r,g", [(1100, 5896, 512, 64, 64), (2148, 4096, 1024, 0, 128), (1024, 7168, 640, 128, 128)])
+def test_gemm_large_m_tile_edges(m, n, k, r, g):
+    """The 256 x 128 tile of the M >= 2048 tier with everything ragged: M not a multiple of 256, N not a multiple of 128,
+    group size 64, 64 / 0 outlier columns, a K loop barely longer than the DMA ring -- full output vs the oracle."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=m + n, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=9)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                 t.get("oweight") if r else None, t["bias"])
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == "gemm_v3_256x128", variant
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None,
+                          bufs["bias"], g).astype(np.float64)
+    assert rel_err(y.cpu().numpy(), yref) < REL_TOL

@@ -38,11 +38,12 @@ def _compare(got, ref, tokens, nll=True):
 
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_engine_7b_first_tokens(model7b, use_graph):
-    """24 tokens from position 0 (one attention block per head throughout): hipGraph replay and eager launches."""
+    """96 tokens from position 0 (one attention block per head throughout): hipGraph replay and eager launches.  (The mean
+    NLL of a run is noise-limited at ~ logit error / sqrt(T): 24 tokens sit at 0.3-1.1e-3 from build to build, 96 at half that.)"""
     from qeft_amd.llama import DecodeEngine
     model, dense = model7b
     eng = DecodeEngine(model, use_graph=use_graph)
-    tokens = torch.randint(0, model.shape.vocab, (24,), generator=torch.Generator().manual_seed(1)).to(DEV)
+    tokens = torch.randint(0, model.shape.vocab, (96,), generator=torch.Generator().manual_seed(1)).to(DEV)
     got = eng.teacher_forced_logits(tokens)
     ref = model.forward_dense_reference(tokens, dense)
     torch.cuda.synchronize()
