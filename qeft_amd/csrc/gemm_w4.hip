@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
             for (int j = 0; j < 4; ++j) bf[j][w] = as_u32(wd[j]);
         }
     };
-    auto mma_tile = [&](int t, const u32x4 (&bf)[4]) {
+    auto mma_tile = [&](int t, const u32x4 (&bf)[4]) {      // plain form (outlier tiles)
         const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
@@ -552,29 +552,88 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
                                                                 __builtin_bit_cast(h8, bf[j]), acc[mt], 0, 0, 0);
     };
 
-    // ---- prologue: three k-tiles in flight, the first two landed, B of tile 0 in registers
+    // ---- prologue: three k-tiles in flight, the first landed, its B in registers
     constexpr int LEAD = G3_ST - 1;
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
         if (t < qtiles) stage(t);
-    u32x4 bcur[4], bnxt[4];
+    u32x4 bA[4], bB[4];        // B fragments of the even / odd k-tiles
+    u32x4 fa[4], fb[4];        // A fragments, two m-tiles in rotation
     wait_tiles(min(qtiles, LEAD) - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (qtiles > 0) dequant_tile(0, bcur);
+    if (qtiles > 0) {
+        dequant_tile(0, bA);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[j] = *(const u32x4*)(lds + a_rd[j]);
+    }
 
-    // ---- main loop: at the top of iteration t the tiles <= t are visible; make tile t + 1 visible (its B is dequantised
-    //      during this iteration), refill the stage of tile t - 1 with tile t + 3, then 32 MFMAs on tile t
-    for (int t = 0; t < qtiles; ++t) {
+    // One k-tile = 8 phases (one per 32-row m-tile), each: 4 MFMAs on the fragments fetched during the previous phase,
+    // the fetch of the next m-tile's fragments (the last phase fetches m-tile 0 of k-tile t + 1), one eighth of the
+    // dequantisation of k-tile t + 1's B and one eighth of the DMA of k-tile t + 3.  With one wave per SIMD nothing else
+    // hides the VALU / LDS / DMA issue, so they are dealt over the MFMA stream by hand; sched_barrier keeps hipcc from
+    // regrouping them into one VALU block, one DMA block and one MFMA block (the first build: 62 % of the 128-row rate).
+    auto tile_body = [&](int t, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
+        const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_STAGE;
+        const bool more = t + 1 < qtiles, refill = t + LEAD < qtiles;
+        const uint32_t rbase = lds0 + (uint32_t)((t + LEAD) & (G3_ST - 1)) * G3_STAGE;
+        const uint8_t* const rsrc = (const uint8_t*)x + (size_t)(t + LEAD) * (BK * 2);
+        u32x4 q = {0u, 0u, 0u, 0u};
+        h2 sc = {(f16)0.f, (f16)0.f}, zc = sc;
+        if (more) {
+            q = *(const u32x4*)(sn + b_rd);
+            sc = splat(*(const f16*)(sn + s_rd));
+            zc = splat(*(const f16*)(sn + s_rd + 256));
+        }
+        h2 qx[4];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            u32x4 (&cur)[4] = (mt & 1) ? fb : fa;
+            u32x4 (&nxt)[4] = (mt & 1) ? fa : fb;
+            if (mt < 7) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
+            } else if (more) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
+            }
+            if (refill) {
+                g3_dma16(rsrc, a_off[mt], rbase + (uint32_t)wave * 8192u + (uint32_t)mt * 1024u);
+                if (mt == 0) {
+                    g3_dma16(qw + (size_t)(t + LEAD) * 128, b_off, rbase + G3_A + (uint32_t)wave * 1024u);
+                    if (wave < 2)
+                        g3_dma4(sz_base + (size_t)(((t + LEAD) * BK) >> gshift) * N * 2, s_off, rbase + G3_A + G3_B + (uint32_t)wave * 256u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
+                                                                acc[mt], 0, 0, 0);
+            if (more) {                     // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
+                if ((mt & 1) == 0) {
+                    nib8_to_q(q[mt >> 1], qx);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bn[j][mt >> 1] = as_u32(__builtin_elementwise_fma(qx[j], sc, zc));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto top = [&](int t) {
         // issued so far: tiles <= t + LEAD - 1; tile t + 1 must have landed -> only tiles t + 2 .. may still be in flight
         wait_tiles(max(0, min(LEAD - 2, qtiles - 2 - t)));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + LEAD < qtiles) stage(t + LEAD);
-        if (t + 1 < qtiles) dequant_tile(t + 1, bnxt);
-        mma_tile(t, bcur);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bcur[j] = bnxt[j];
+    };
+    for (int t = 0; t < qtiles; t += 2) {
+        top(t);
+        tile_body(t, bA, bB);
+        if (t + 1 < qtiles) {
+            top(t + 1);
+            tile_body(t + 1, bB, bA);
+        }
     }
 
     // ---- fp16 outlier k-tiles (2 for r = 128): the pipeline is empty; A by DMA into stage 0, B fragments from oweight
