@@ -417,16 +417,18 @@ __global__ __launch_bounds__(64 * NWV) void gemm_w4_kernel_v2(const f16* __restr
 // whatever the tile height, so 256 rows halve the VALU, LDS-DMA and barrier work per MFMA (32 MFMAs per k-tile and wave
 // against 16).  The grid is one block per CU at 2048 x 4096 (256 blocks), dealt so that an XCD works on one 256-row
 // block of the activations (2 MB at K = 4096: resident in its 4 MB L2) while the packed weights stream past.
-//   * LDS: 4 stages of [A 32 KB | packed B 4 KB | scales + scaled zeros of the tile's group 512 B] = 146 KB; three k-tiles
-//     in flight by LDS-DMA behind a counted s_waitcnt, ONE s_barrier per k-tile (32 MFMAs per wave between barriers).
+//   * LDS: a 4-stage ring of activation tiles (32 KB each, three in flight from L2) and a 6-slot ring of the packed weight
+//     tiles + their scales (4.5 KB each, five in flight: they come from HBM / MALL, and a k-tile gated by a 2-3 us weight
+//     fetch with only two tiles of lead ran the first version at a third of the MFMA rate); all by LDS-DMA behind a
+//     counted s_waitcnt, ONE s_barrier per k-tile (32 MFMAs per wave between barriers).
 //   * a wave DMAs and reads its OWN 1 KB of the packed B tile (its 32 columns), so B needs no cross-wave hand-off;
 //     the B fragments of k-tile t + 1 are dequantised in registers while the MFMAs of k-tile t run.
 //   * fp16 outlier k-tiles, bias and the fp16 epilogue as in gemm_w4_kernel_v2.
 // ---------------------------------------------------------------------------------------------------
-constexpr int G3_BM = 256, G3_BN = 128, G3_ST = 4;
+constexpr int G3_BM = 256, G3_BN = 128, G3_ST = 4, G3_BST = 6;
 constexpr int G3_A = G3_BM * BK * 2, G3_B = G3_BN * BK / 2, G3_S = 512;
-constexpr int G3_STAGE = G3_A + G3_B + G3_S;           // 37376 bytes
-constexpr size_t G3_SMEM = (size_t)G3_ST * G3_STAGE;   // 149504 bytes
+constexpr int G3_BOFF = G3_ST * G3_A, G3_SOFF = G3_BOFF + G3_BST * G3_B;      // [4 x A 32 KB][6 x B 4 KB][6 x scales 512 B]
+constexpr size_t G3_SMEM = (size_t)G3_SOFF + G3_BST * G3_S;                   // 158720 bytes
 
 // n DMA pieces of 1 KB: lane's 16 bytes at (sbase + voff_i) -> LDS[lds_dst + 1024 i + 16 lane], i = 0..7 (one asm statement:
 // M0 is written and read inside it; the pieces stay invisible to hipcc's s_waitcnt bookkeeping and are counted by hand)
@@ -497,23 +499,24 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
     const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
     const uint8_t* const sz_base = (const uint8_t*)(wave == 0 ? scales : zeros);
 
-    auto stage = [&](int t) {              // 10 DMA instructions for waves 0 / 1, 9 for waves 2 / 3
-        const uint32_t base = lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_STAGE;
-        g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, base + (uint32_t)wave * 8192u);
-        g3_dma16(qw + (size_t)t * 128, b_off, base + G3_A + (uint32_t)wave * 1024u);
-        if (wave < 2)
-            g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, base + G3_A + G3_B + (uint32_t)wave * 256u);
+    // LDS addresses of k-tile t: activation stage t % 4, weight / scale slot t % 6 (slot counters, no division in the loop)
+    auto stage_a = [&](int t) {            // 8 DMA instructions per wave
+        g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_A + (uint32_t)wave * 8192u);
     };
-    auto wait_tiles = [&](int younger) {   // all but the `younger` most recent stage() calls of this wave have landed
-        if (wave < 2) {
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    auto stage_b = [&](int t, int slot) {  // 1 (waves 2 / 3) or 2 (waves 0 / 1) DMA instructions
+        g3_dma16(qw + (size_t)t * 128, b_off, lds0 + G3_BOFF + (uint32_t)slot * G3_B + (uint32_t)wave * 1024u);
+        if (wave < 2)
+            g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + G3_SOFF + (uint32_t)slot * G3_S + (uint32_t)wave * 256u);
+    };
+    // In-order completion: at the top of iteration t the activations of k-tile t + 1 (the LAST thing iteration t - 2 issued)
+    // must have landed; younger than them is exactly what iteration t - 1 issued: [weights / scales of k-tile t + 4: 2 pieces
+    // on waves 0 / 1, 1 on waves 2 / 3] then [8 activation pieces of k-tile t + 2].  The weights of k-tile t + 1 are older
+    // still (iteration t - 4).  Towards the end the refills stop (weights first).
+    auto wait_prev = [&](bool prev_a, bool prev_b) {
+        if (!prev_a) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (!prev_b) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (wave < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     };
 
     f32x16 acc[8];
@@ -526,14 +529,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
     uint32_t a_rd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_rd[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));
-    const uint32_t b_rd = (uint32_t)(G3_A + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);
-    const uint32_t s_rd = (uint32_t)(G3_A + G3_B + nloc * 2);
+    const uint32_t b_rd = (uint32_t)(G3_BOFF + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);      // + slot * G3_B
+    const uint32_t s_rd = (uint32_t)(G3_SOFF + nloc * 2);                                          // + slot * G3_S
 
     // B fragments of a k-tile: k-step j contracts the 8 consecutive k h*32 + 8j .. +7 = pair j of each of the 4 nibble words
-    auto dequant_tile = [&](int t, u32x4 (&bf)[4]) {
-        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
-        const u32x4 q = *(const u32x4*)(st + b_rd);
-        const h2 sc = splat(*(const f16*)(st + s_rd)), zc = splat(*(const f16*)(st + s_rd + 256));
+    auto dequant_tile = [&](int slot, u32x4 (&bf)[4]) {
+        const u32x4 q = *(const u32x4*)(lds + b_rd + slot * G3_B);
+        const h2 sc = splat(*(const f16*)(lds + s_rd + slot * G3_S)), zc = splat(*(const f16*)(lds + s_rd + slot * G3_S + 256));
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             h2 wd[4];
@@ -542,8 +544,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
             for (int j = 0; j < 4; ++j) bf[j][w] = as_u32(wd[j]);
         }
     };
-    auto mma_tile = [&](int t, const u32x4 (&bf)[4]) {      // plain form (outlier tiles)
-        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
+    auto mma_tile = [&](const uint8_t* st, const u32x4 (&bf)[4]) {      // plain form (outlier tiles)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
@@ -552,14 +553,19 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
                                                                 __builtin_bit_cast(h8, bf[j]), acc[mt], 0, 0, 0);
     };
 
-    // ---- prologue: three k-tiles in flight, the first landed, its B in registers
-    constexpr int LEAD = G3_ST - 1;
+    // ---- prologue: weights / scales of the first 5 k-tiles, then activations of the first 3; the first landed, its B in registers
+    constexpr int LEAD = G3_ST - 1, LEAD_B = G3_BST - 1;
+#pragma unroll
+    for (int t = 0; t < LEAD_B; ++t)
+        if (t < qtiles) stage_b(t, t);
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
-        if (t < qtiles) stage(t);
+        if (t < qtiles) stage_a(t);
     u32x4 bA[4], bB[4];        // B fragments of the even / odd k-tiles
     u32x4 fa[4], fb[4];        // A fragments, two m-tiles in rotation
-    wait_tiles(min(qtiles, LEAD) - 1);
+    // activations of tile 0 landed <=> at most the (min(qtiles, 3) - 1) * 8 youngest pieces outstanding
+    if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (qtiles > 0) {
@@ -573,18 +579,19 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
     // dequantisation of k-tile t + 1's B and one eighth of the DMA of k-tile t + 3.  With one wave per SIMD nothing else
     // hides the VALU / LDS / DMA issue, so they are dealt over the MFMA stream by hand; sched_barrier keeps hipcc from
     // regrouping them into one VALU block, one DMA block and one MFMA block (the first build: 62 % of the 128-row rate).
-    auto tile_body = [&](int t, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
-        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_STAGE;
-        const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_STAGE;
+    // slot_n: weight slot of k-tile t + 1; slot_f: the slot k-tile t + 5 is fetched into (held k-tile t - 1)
+    auto tile_body = [&](int t, int slot_n, int slot_f, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_A;
+        const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_A;
         const bool more = t + 1 < qtiles, refill = t + LEAD < qtiles;
-        const uint32_t rbase = lds0 + (uint32_t)((t + LEAD) & (G3_ST - 1)) * G3_STAGE;
+        const uint32_t rbase = lds0 + (uint32_t)((t + LEAD) & (G3_ST - 1)) * G3_A + (uint32_t)wave * 8192u;
         const uint8_t* const rsrc = (const uint8_t*)x + (size_t)(t + LEAD) * (BK * 2);
         u32x4 q = {0u, 0u, 0u, 0u};
         h2 sc = {(f16)0.f, (f16)0.f}, zc = sc;
         if (more) {
-            q = *(const u32x4*)(sn + b_rd);
-            sc = splat(*(const f16*)(sn + s_rd));
-            zc = splat(*(const f16*)(sn + s_rd + 256));
+            q = *(const u32x4*)(lds + b_rd + slot_n * G3_B);
+            sc = splat(*(const f16*)(lds + s_rd + slot_n * G3_S));
+            zc = splat(*(const f16*)(lds + s_rd + slot_n * G3_S + 256));
         }
         h2 qx[4];
 #pragma unroll
@@ -598,14 +605,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
             }
-            if (refill) {
-                g3_dma16(rsrc, a_off[mt], rbase + (uint32_t)wave * 8192u + (uint32_t)mt * 1024u);
-                if (mt == 0) {
-                    g3_dma16(qw + (size_t)(t + LEAD) * 128, b_off, rbase + G3_A + (uint32_t)wave * 1024u);
-                    if (wave < 2)
-                        g3_dma4(sz_base + (size_t)(((t + LEAD) * BK) >> gshift) * N * 2, s_off, rbase + G3_A + G3_B + (uint32_t)wave * 256u);
-                }
-            }
+            if (mt == 0 && t + LEAD_B < qtiles) stage_b(t + LEAD_B, slot_f);      // BEFORE the A pieces: see top()
+            if (refill) g3_dma16(rsrc, a_off[mt], rbase + (uint32_t)mt * 1024u);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
@@ -621,18 +622,31 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto top = [&](int t) {
-        // issued so far: tiles <= t + LEAD - 1; tile t + 1 must have landed -> only tiles t + 2 .. may still be in flight
-        wait_tiles(max(0, min(LEAD - 2, qtiles - 2 - t)));
+    auto top = [&](int t) {                // t >= 1
+        wait_prev((t - 1) + LEAD < qtiles, (t - 1) + LEAD_B < qtiles);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    int slot_n = 1 % G3_BST, slot_f = LEAD_B % G3_BST;      // (t + 1) % 6 and (t + 5) % 6 at t = 0
+    auto bump = [&]() {
+        slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1;
+        slot_f = slot_f + 1 == G3_BST ? 0 : slot_f + 1;
+    };
     for (int t = 0; t < qtiles; t += 2) {
-        top(t);
-        tile_body(t, bA, bB);
+        if (t == 0) {      // the prologue's issues (3 tiles of A) are the youngest: tile 1's activations = all but the last 8
+            if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            top(t);
+        }
+        tile_body(t, slot_n, slot_f, bA, bB);
+        bump();
         if (t + 1 < qtiles) {
             top(t + 1);
-            tile_body(t + 1, bB, bA);
+            tile_body(t + 1, slot_n, slot_f, bB, bA);
+            bump();
         }
     }
 
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
     if (OUTL) {
         for (int t = qtiles; t < ktiles; ++t) {
             __builtin_amdgcn_s_barrier();          // every wave finished reading the stage about to be overwritten
-            g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)wave * 8192u);
+            g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)wave * 8192u);      // A stage 0
             u32x4 bf[4];
             const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + (t * BK + h * 32 - kq));
 #pragma unroll
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            mma_tile(0, bf);
+            mma_tile(lds, bf);
         }
     }
 
@@ -699,7 +713,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
     {
         static const int force_v3 = getenv("QEFT_GEMM_V3") ? atoi(getenv("QEFT_GEMM_V3")) : -1;
         const int mb = (M + G3_BM - 1) / G3_BM, nb = (N + G3_BN - 1) / G3_BN;
-        const bool ok3 = K / BK >= G3_ST && K % BK == 0 && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && G >= 64 &&
+        const bool ok3 = K / BK >= G3_BST && K % BK == 0 && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && G >= 64 &&
                          N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
         if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024))) {
             auto go3 = [&](auto kern) -> hipError_t {
