@@ -409,8 +409,8 @@ __global__ __launch_bounds__(64 * NWV) void gemm_w4_kernel_v2(const f16* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Forward GEMM, large-M version (M >= ~2048): 256 (m) x 128 (n) x 64 (k) block tile, 4 waves side by side along N, each
-// 256 rows x 32 columns = 8 MFMA 32x32 tiles: ONE wave per SIMD with the whole register file.
+// Forward GEMM, large-M version (M >= ~2048): 256 (m) x 128 (n) x 64 (k) block tile, 4 compute waves side by side along N,
+// each 256 rows x 32 columns = 8 MFMA 32x32 tiles, plus 4 loader waves (one compute + one loader wave per SIMD).
 //
 // Why this shape (profiles/r01_gemm_pmc.txt: the 128-row tiles issue ~0.85 VALU cycles per MFMA cycle with two waves
 // per SIMD and run the matrix pipe at 57 %): the dequantisation of a wave's 32 columns x 64 k costs the same ~56 VALU
@@ -461,15 +461,18 @@ __device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32
 }
 
 template <bool OUTL>
-__global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
+__global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
                                                            f16* __restrict__ y, int M, int N, int K, int G, int n_out, int NB) {
+    // 8 waves, two per SIMD with fixed roles: waves 0..3 compute (wave w: columns 32 w .. 32 w + 31 of the tile, all 256 rows),
+    // waves 4..7 load (wave 4 + l: activation pieces 8 l .. 8 l + 7, the packed weights of compute wave l, scales / zeros).
+    // An LDS-DMA instruction holds its wave for 100-200 cycles at issue; in the compute waves' own stream (first version)
+    // that stalled the matrix pipe 8 times per k-tile.  Loader waves absorb it in the shadow of their SIMD partner's MFMAs.
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
     // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through consecutive tiles of one row block
     const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
     const int c = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
@@ -477,47 +480,83 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
     const int ktiles = K / BK;
     const int kq = K - (OUTL ? n_out : 0);
     const int qtiles = kq / BK;            // INT4 k-tiles [0, qtiles); fp16 outlier k-tiles [qtiles, ktiles)
-    const int gshift = 31 - __builtin_clz(G);
+    constexpr int LEAD = G3_ST - 1, LEAD_B = G3_BST - 1;
 
+    if (wave >= 4) {
+        // =========================================================== loader waves
+        const int l = wave - 4;
+        const int gshift = 31 - __builtin_clz(G);
+        // A piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7)
+        uint32_t a_off[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (l * 8 + i) * 8 + (lane >> 3);
+            const int grow = min(bm0 + row, M - 1);
+            a_off[i] = (uint32_t)grow * (uint32_t)K * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+        // B: the 1 KB of compute wave l's 32 columns (row groups bn0/4 + 8l ..): lane -> (row group lane/8, 16-byte piece lane%8)
+        const int brg = min(bn0 / 4 + l * 8 + (lane >> 3), N / 4 - 1);
+        const uint32_t b_off = (uint32_t)brg * (uint32_t)K * 2u + (uint32_t)(lane & 7) * 16u;
+        // scales (l == 0) / scaled zeros (l == 1) of the tile's group: 128 columns x 2 B = 64 lanes x 4 B
+        const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
+        const uint8_t* const sz_base = (const uint8_t*)(l == 0 ? scales : zeros);
+        auto stage_a = [&](int t) {            // 8 DMA instructions
+            g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_A + (uint32_t)l * 8192u);
+        };
+        auto stage_b = [&](int t, int slot) {  // 2 (l < 2) or 1 DMA instructions
+            g3_dma16(qw + (size_t)t * 128, b_off, lds0 + G3_BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
+            if (l < 2)
+                g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + G3_SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
+        };
+        // In-order completion: at the top of iteration t the activations of k-tile t + 1 (the LAST thing iteration t - 2
+        // issued) must have landed; younger than them is exactly what iteration t - 1 issued: [weights / scales of k-tile
+        // t + 4: 2 pieces for l < 2, else 1] then [8 activation pieces of k-tile t + 2].  The weights of k-tile t + 1 are
+        // older still (iteration t - 4).  Towards the end the refills stop (weights first).
+        auto wait_prev = [&](bool prev_a, bool prev_b) {
+            if (!prev_a) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (!prev_b) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (l < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        };
+#pragma unroll
+        for (int t = 0; t < LEAD_B; ++t)
+            if (t < qtiles) stage_b(t, t);
+#pragma unroll
+        for (int t = 0; t < LEAD; ++t)
+            if (t < qtiles) stage_a(t);
+        // activations of k-tile 0 landed <=> at most the 16 youngest pieces (k-tiles 1, 2) outstanding
+        if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot_f = LEAD_B % G3_BST;
+        for (int t = 0; t < qtiles; ++t) {
+            if (t == 0) {
+                if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // k-tile 1: all but k-tile 2's pieces
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                wait_prev((t - 1) + LEAD < qtiles, (t - 1) + LEAD_B < qtiles);
+            }
+            __builtin_amdgcn_s_barrier();      // k-tile t + 1 visible to everyone; everyone is done with k-tile t - 1
+            if (t + LEAD_B < qtiles) stage_b(t + LEAD_B, slot_f);      // BEFORE the activation pieces: see wait_prev
+            if (t + LEAD < qtiles) stage_a(t + LEAD);
+            slot_f = slot_f + 1 == G3_BST ? 0 : slot_f + 1;
+        }
+        if (OUTL) {
+            for (int t = qtiles; t < ktiles; ++t) {
+                __builtin_amdgcn_s_barrier();          // every compute wave finished reading stage 0
+                g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)l * 8192u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        return;
+    }
+
+    // =============================================================== compute waves
+    const int r = lane & 31, h = lane >> 5;
     const int nloc = wave * 32 + r;
     const int ncol = min(bn0 + nloc, N - 1);
     const bool nok = bn0 + nloc < N;
-
-    // ---- DMA sources (32-bit lane offsets from uniform bases).  A piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk
-    //      lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7); wave w stages pieces 8w .. 8w + 7.
-    uint32_t a_off[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (wave * 8 + i) * 8 + (lane >> 3);
-        const int grow = min(bm0 + row, M - 1);
-        a_off[i] = (uint32_t)grow * (uint32_t)K * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
-    }
-    // B: wave w stages the 1 KB of ITS 32 columns (row groups bn0/4 + 8w ..): lane -> (row group lane/8, 16-byte piece lane%8)
-    const int brg = min(bn0 / 4 + wave * 8 + (lane >> 3), N / 4 - 1);
-    const uint32_t b_off = (uint32_t)brg * (uint32_t)K * 2u + (uint32_t)(lane & 7) * 16u;
-    // scales (wave 0) / scaled zeros (wave 1) of the tile's group: 128 columns x 2 B = 64 lanes x 4 B
-    const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
-    const uint8_t* const sz_base = (const uint8_t*)(wave == 0 ? scales : zeros);
-
-    // LDS addresses of k-tile t: activation stage t % 4, weight / scale slot t % 6 (slot counters, no division in the loop)
-    auto stage_a = [&](int t) {            // 8 DMA instructions per wave
-        g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_A + (uint32_t)wave * 8192u);
-    };
-    auto stage_b = [&](int t, int slot) {  // 1 (waves 2 / 3) or 2 (waves 0 / 1) DMA instructions
-        g3_dma16(qw + (size_t)t * 128, b_off, lds0 + G3_BOFF + (uint32_t)slot * G3_B + (uint32_t)wave * 1024u);
-        if (wave < 2)
-            g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + G3_SOFF + (uint32_t)slot * G3_S + (uint32_t)wave * 256u);
-    };
-    // In-order completion: at the top of iteration t the activations of k-tile t + 1 (the LAST thing iteration t - 2 issued)
-    // must have landed; younger than them is exactly what iteration t - 1 issued: [weights / scales of k-tile t + 4: 2 pieces
-    // on waves 0 / 1, 1 on waves 2 / 3] then [8 activation pieces of k-tile t + 2].  The weights of k-tile t + 1 are older
-    // still (iteration t - 4).  Towards the end the refills stop (weights first).
-    auto wait_prev = [&](bool prev_a, bool prev_b) {
-        if (!prev_a) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (!prev_b) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (wave < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    };
 
     f32x16 acc[8];
 #pragma unroll
@@ -525,7 +564,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    // per-lane LDS offsets inside a stage: A fragment of m-tile mt, k-step j at a_rd[j] + mt * 4096
+    // per-lane LDS offsets: A fragment of m-tile mt, k-step j at stage + a_rd[j] + mt * 4096
     uint32_t a_rd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_rd[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));
@@ -553,20 +592,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
                                                                 __builtin_bit_cast(h8, bf[j]), acc[mt], 0, 0, 0);
     };
 
-    // ---- prologue: weights / scales of the first 5 k-tiles, then activations of the first 3; the first landed, its B in registers
-    constexpr int LEAD = G3_ST - 1, LEAD_B = G3_BST - 1;
-#pragma unroll
-    for (int t = 0; t < LEAD_B; ++t)
-        if (t < qtiles) stage_b(t, t);
-#pragma unroll
-    for (int t = 0; t < LEAD; ++t)
-        if (t < qtiles) stage_a(t);
     u32x4 bA[4], bB[4];        // B fragments of the even / odd k-tiles
     u32x4 fa[4], fb[4];        // A fragments, two m-tiles in rotation
-    // activations of tile 0 landed <=> at most the (min(qtiles, 3) - 1) * 8 youngest pieces outstanding
-    if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();              // k-tile 0 visible
     asm volatile("" ::: "memory");
     if (qtiles > 0) {
         dequant_tile(0, bA);
@@ -575,17 +603,13 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
     }
 
     // One k-tile = 8 phases (one per 32-row m-tile), each: 4 MFMAs on the fragments fetched during the previous phase,
-    // the fetch of the next m-tile's fragments (the last phase fetches m-tile 0 of k-tile t + 1), one eighth of the
-    // dequantisation of k-tile t + 1's B and one eighth of the DMA of k-tile t + 3.  With one wave per SIMD nothing else
-    // hides the VALU / LDS / DMA issue, so they are dealt over the MFMA stream by hand; sched_barrier keeps hipcc from
-    // regrouping them into one VALU block, one DMA block and one MFMA block (the first build: 62 % of the 128-row rate).
-    // slot_n: weight slot of k-tile t + 1; slot_f: the slot k-tile t + 5 is fetched into (held k-tile t - 1)
-    auto tile_body = [&](int t, int slot_n, int slot_f, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+    // the fetch of the next m-tile's fragments (the last phase fetches m-tile 0 of k-tile t + 1) and one eighth of the
+    // dequantisation of k-tile t + 1's B; sched_barrier keeps hipcc from regrouping them into one VALU block and one MFMA
+    // block.  slot_n: weight slot of k-tile t + 1.
+    auto tile_body = [&](int t, int slot_n, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
         const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_A;
         const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_A;
-        const bool more = t + 1 < qtiles, refill = t + LEAD < qtiles;
-        const uint32_t rbase = lds0 + (uint32_t)((t + LEAD) & (G3_ST - 1)) * G3_A + (uint32_t)wave * 8192u;
-        const uint8_t* const rsrc = (const uint8_t*)x + (size_t)(t + LEAD) * (BK * 2);
+        const bool more = t + 1 < qtiles;
         u32x4 q = {0u, 0u, 0u, 0u};
         h2 sc = {(f16)0.f, (f16)0.f}, zc = sc;
         if (more) {
@@ -605,8 +629,6 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
             }
-            if (mt == 0 && t + LEAD_B < qtiles) stage_b(t + LEAD_B, slot_f);      // BEFORE the A pieces: see top()
-            if (refill) g3_dma16(rsrc, a_off[mt], rbase + (uint32_t)mt * 1024u);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
@@ -622,45 +644,29 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel_v3(const f16* __restrict__
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto top = [&](int t) {                // t >= 1
-        wait_prev((t - 1) + LEAD < qtiles, (t - 1) + LEAD_B < qtiles);
+    int slot_n = 1 % G3_BST;
+    for (int t = 0; t < qtiles; t += 2) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-    };
-    int slot_n = 1 % G3_BST, slot_f = LEAD_B % G3_BST;      // (t + 1) % 6 and (t + 5) % 6 at t = 0
-    auto bump = [&]() {
+        tile_body(t, slot_n, bA, bB);
         slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1;
-        slot_f = slot_f + 1 == G3_BST ? 0 : slot_f + 1;
-    };
-    for (int t = 0; t < qtiles; t += 2) {
-        if (t == 0) {      // the prologue's issues (3 tiles of A) are the youngest: tile 1's activations = all but the last 8
-            if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 < qtiles) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-        } else {
-            top(t);
-        }
-        tile_body(t, slot_n, slot_f, bA, bB);
-        bump();
-        if (t + 1 < qtiles) {
-            top(t + 1);
-            tile_body(t + 1, slot_n, slot_f, bB, bA);
-            bump();
+            tile_body(t + 1, slot_n, bB, bA);
+            slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1;
         }
     }
 
     // ---- fp16 outlier k-tiles (2 for r = 128): the pipeline is empty; A by DMA into stage 0, B fragments from oweight
     if (OUTL) {
         for (int t = qtiles; t < ktiles; ++t) {
-            __builtin_amdgcn_s_barrier();          // every wave finished reading the stage about to be overwritten
-            g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)wave * 8192u);      // A stage 0
+            __builtin_amdgcn_s_barrier();          // (loaders: every compute wave finished reading stage 0)
             u32x4 bf[4];
             const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + (t * BK + h * 32 - kq));
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = p[j];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();          // the loaders' pieces of this k-tile landed
             asm volatile("" ::: "memory");
             mma_tile(lds, bf);
         }
@@ -719,7 +725,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             auto go3 = [&](auto kern) -> hipError_t {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_SMEM);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(kern, dim3(mb * nb), dim3(256), G3_SMEM, st, (const f16*)x, (const uint8_t*)qw,
+                hipLaunchKernelGGL(kern, dim3(mb * nb), dim3(512), G3_SMEM, st, (const f16*)x, (const uint8_t*)qw,
                                    (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
                                    (f16*)y, M, N, K, G, outl ? n_out : 0, nb);
                 return hipGetLastError();
