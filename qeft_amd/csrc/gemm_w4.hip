@@ -19,6 +19,7 @@
 //   * k-tiles inside the last n_out columns take their B fragments from the fp16 oweight slice instead
 //     of the (dead) nibbles: same MFMA stream, no second kernel, no read-modify-write of y.
 #include <cstdlib>
+#include <type_traits>
 
 #include "qeft_common.h"
 
@@ -602,22 +603,22 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         for (int j = 0; j < 4; ++j) fa[j] = *(const u32x4*)(lds + a_rd[j]);
     }
 
-    // One k-tile = 8 phases (one per 32-row m-tile), each: 4 MFMAs on the fragments fetched during the previous phase,
-    // the fetch of the next m-tile's fragments (the last phase fetches m-tile 0 of k-tile t + 1) and one eighth of the
-    // dequantisation of k-tile t + 1's B; sched_barrier keeps hipcc from regrouping them into one VALU block and one MFMA
-    // block.  slot_n: weight slot of k-tile t + 1.
-    auto tile_body = [&](int t, int slot_n, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+    // One k-tile = 8 phases (one per 32-row m-tile), each: the fetch of the NEXT m-tile's fragments (the last phase fetches
+    // m-tile 0 of k-tile t + 1), then 4 MFMAs on the fragments fetched during the previous phase and one eighth of the
+    // dequantisation of k-tile t + 1's B.  The sched_barriers pin that order: left alone, hipcc sinks the fetches behind the
+    // third MFMA (one MFMA of lead instead of a whole phase; lgkmcnt waits were 22 % of the compute waves' time) or regroups
+    // everything into one VALU block and one MFMA block.  MORE = false: the last INT4 k-tile (nothing to prepare).
+    auto tile_body = [&](auto more_tag, int t, int slot_n, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_A;
         const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_A;
-        const bool more = t + 1 < qtiles;
-        u32x4 q = {0u, 0u, 0u, 0u};
-        h2 sc = {(f16)0.f, (f16)0.f}, zc = sc;
-        if (more) {
+        u32x4 q;
+        h2 sc, zc, qx[4];
+        if (MORE) {
             q = *(const u32x4*)(lds + b_rd + slot_n * G3_B);
             sc = splat(*(const f16*)(lds + s_rd + slot_n * G3_S));
             zc = splat(*(const f16*)(lds + s_rd + slot_n * G3_S + 256));
         }
-        h2 qx[4];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             u32x4 (&cur)[4] = (mt & 1) ? fb : fa;
@@ -625,15 +626,16 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             if (mt < 7) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
-            } else if (more) {
+            } else if (MORE) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
                                                                 acc[mt], 0, 0, 0);
-            if (more) {                     // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
+            if (MORE) {                     // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
                 if ((mt & 1) == 0) {
                     nib8_to_q(q[mt >> 1], qx);
                 } else {
@@ -644,18 +646,36 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    int slot_n = 1 % G3_BST;
-    for (int t = 0; t < qtiles; t += 2) {
+    auto sync_tile = [&]() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        tile_body(t, slot_n, bA, bB);
-        slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1;
-        if (t + 1 < qtiles) {
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            tile_body(t + 1, slot_n, bB, bA);
-            slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1;
+    };
+    int slot_n = 1 % G3_BST;
+    auto bump = [&]() { slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1; };
+    {   // qtiles >= 4 (launcher).  An odd count runs one leading k-tile and moves its B back to bA, so that the loop and the
+        // final pair keep static register roles; the last k-tile prepares nothing.
+        int t = 0;
+        if (qtiles & 1) {
+            sync_tile();
+            tile_body(std::true_type{}, 0, slot_n, bA, bB);
+            bump();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bA[j] = bB[j];
+            t = 1;
         }
+        for (; t + 2 < qtiles; t += 2) {
+            sync_tile();
+            tile_body(std::true_type{}, t, slot_n, bA, bB);
+            bump();
+            sync_tile();
+            tile_body(std::true_type{}, t + 1, slot_n, bB, bA);
+            bump();
+        }
+        sync_tile();
+        tile_body(std::true_type{}, t, slot_n, bA, bB);
+        bump();
+        sync_tile();
+        tile_body(std::false_type{}, t + 1, slot_n, bB, bA);
     }
 
     // ---- fp16 outlier k-tiles (2 for r = 128): the pipeline is empty; A by DMA into stage 0, B fragments from oweight
