@@ -430,6 +430,7 @@ constexpr int G3_BM = 256, G3_BN = 128, G3_ST = 4, G3_BST = 6;
 constexpr int G3_A = G3_BM * BK * 2, G3_B = G3_BN * BK / 2, G3_S = 512;
 constexpr int G3_BOFF = G3_ST * G3_A, G3_SOFF = G3_BOFF + G3_BST * G3_B;      // [4 x A 32 KB][6 x B 4 KB][6 x scales 512 B]
 constexpr size_t G3_SMEM = (size_t)G3_SOFF + G3_BST * G3_S;                   // 158720 bytes
+constexpr int G3_YP = G3_BN * 2 + 16;     // pitch of the fp16 output tile staged in LDS for the epilogue (256 rows: 68 KB of the ring)
 
 // n DMA pieces of 1 KB: lane's 16 bytes at (sbase + voff_i) -> LDS[lds_dst + 1024 i + 16 lane], i = 0..7 (one asm statement:
 // M0 is written and read inside it; the pieces stay invisible to hipcc's s_waitcnt bookkeeping and are counted by hand)
@@ -461,7 +462,9 @@ __device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32
                  : "=&s"(keep) : "s"(sbase), "s"(lds_dst), "v"(voff) : "memory");
 }
 
-template <bool OUTL>
+// ABL (lab only, QEFT_GEMM_ABL): 1 = the loader waves issue no DMA, 2 = the compute waves skip their k-tile bodies -- wrong
+// results, but the two timings say which side of the block sets the pace (profiles/r02_gemm_v3_ablation.txt).
+template <bool OUTL, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
@@ -502,9 +505,11 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
         const uint8_t* const sz_base = (const uint8_t*)(l == 0 ? scales : zeros);
         auto stage_a = [&](int t) {            // 8 DMA instructions
+            if (ABL == 1) return;
             g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_A + (uint32_t)l * 8192u);
         };
         auto stage_b = [&](int t, int slot) {  // 2 (l < 2) or 1 DMA instructions
+            if (ABL == 1) return;
             g3_dma16(qw + (size_t)t * 128, b_off, lds0 + G3_BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
             if (l < 2)
                 g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + G3_SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
@@ -524,31 +529,23 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             if (t < qtiles) stage_b(t, t);
 #pragma unroll
         for (int t = 0; t < LEAD; ++t)
-            if (t < qtiles) stage_a(t);
+            if (t < ktiles) stage_a(t);
         // activations of k-tile 0 landed <=> at most the 16 youngest pieces (k-tiles 1, 2) outstanding
-        if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (ktiles >= LEAD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int slot_f = LEAD_B % G3_BST;
-        for (int t = 0; t < qtiles; ++t) {
+        for (int t = 0; t < ktiles; ++t) {         // INT4 and fp16 outlier k-tiles alike (the latter have no weight pieces)
             if (t == 0) {
-                if (qtiles >= LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // k-tile 1: all but k-tile 2's pieces
+                if (ktiles >= LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // k-tile 1: all but k-tile 2's pieces
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                wait_prev((t - 1) + LEAD < qtiles, (t - 1) + LEAD_B < qtiles);
+                wait_prev((t - 1) + LEAD < ktiles, (t - 1) + LEAD_B < qtiles);
             }
             __builtin_amdgcn_s_barrier();      // k-tile t + 1 visible to everyone; everyone is done with k-tile t - 1
             if (t + LEAD_B < qtiles) stage_b(t + LEAD_B, slot_f);      // BEFORE the activation pieces: see wait_prev
-            if (t + LEAD < qtiles) stage_a(t + LEAD);
+            if (t + LEAD < ktiles) stage_a(t + LEAD);
             slot_f = slot_f + 1 == G3_BST ? 0 : slot_f + 1;
-        }
-        if (OUTL) {
-            for (int t = qtiles; t < ktiles; ++t) {
-                __builtin_amdgcn_s_barrier();          // every compute wave finished reading stage 0
-                g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)l * 8192u);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
         }
         return;
     }
@@ -557,7 +554,6 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     const int r = lane & 31, h = lane >> 5;
     const int nloc = wave * 32 + r;
     const int ncol = min(bn0 + nloc, N - 1);
-    const bool nok = bn0 + nloc < N;
 
     f32x16 acc[8];
 #pragma unroll
@@ -584,15 +580,6 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             for (int j = 0; j < 4; ++j) bf[j][w] = as_u32(wd[j]);
         }
     };
-    auto mma_tile = [&](const uint8_t* st, const u32x4 (&bf)[4]) {      // plain form (outlier tiles)
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)(st + a_rd[j] + mt * 4096),
-                                                                __builtin_bit_cast(h8, bf[j]), acc[mt], 0, 0, 0);
-    };
-
     u32x4 bA[4], bB[4];        // B fragments of the even / odd k-tiles
     u32x4 fa[4], fb[4];        // A fragments, two m-tiles in rotation
     __builtin_amdgcn_s_barrier();              // k-tile 0 visible
@@ -607,35 +594,59 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // m-tile 0 of k-tile t + 1), then 4 MFMAs on the fragments fetched during the previous phase and one eighth of the
     // dequantisation of k-tile t + 1's B.  The sched_barriers pin that order: left alone, hipcc sinks the fetches behind the
     // third MFMA (one MFMA of lead instead of a whole phase; lgkmcnt waits were 22 % of the compute waves' time) or regroups
-    // everything into one VALU block and one MFMA block.  MORE = false: the last INT4 k-tile (nothing to prepare).
-    auto tile_body = [&](auto more_tag, int t, int slot_n, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
-        constexpr bool MORE = decltype(more_tag)::value;
+    // everything into one VALU block and one MFMA block.
+    // The packed words / scale / zero of k-tile t + 1 are already in registers (qn, sn_, zn_) when the tile starts, and the
+    // last phase fetches those of k-tile t + 2 (landed before barrier t: the loaders issue the weights of k-tile t + 3 ahead
+    // of the activations of k-tile t + 1 they wait for), so nothing the first MFMAs need is issued after the barrier.
+    // TAIL = false: k-tiles t + 1 and t + 2 are INT4 k-tiles (for t = qtiles - 2 the fetch for "t + 2" reads a stale slot and
+    // is never used).  TAIL = true: k-tile t + 1, if there is one, is an fp16 outlier k-tile: its B fragments are plain
+    // global loads from oweight, in flight during this tile's MFMAs -- the outlier k-tiles ride the same activation ring
+    // (their first version, with an empty pipeline around each, cost ~3 us per k-tile: 6 us of a 75 us launch).
+    u32x4 qn;
+    f16 sn_, zn_;
+    auto fetch_b = [&](int slot) {
+        qn = *(const u32x4*)(lds + b_rd + slot * G3_B);
+        sn_ = *(const f16*)(lds + s_rd + slot * G3_S);
+        zn_ = *(const f16*)(lds + s_rd + slot * G3_S + 256);
+    };
+    auto tile_body = [&](auto tail_tag, int t, int slot_n2, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (ABL == 2) return;
         const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_A;
         const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_A;
-        u32x4 q;
-        h2 sc, zc, qx[4];
-        if (MORE) {
-            q = *(const u32x4*)(lds + b_rd + slot_n * G3_B);
-            sc = splat(*(const f16*)(lds + s_rd + slot_n * G3_S));
-            zc = splat(*(const f16*)(lds + s_rd + slot_n * G3_S + 256));
+        const bool has_next = !TAIL || t + 1 < ktiles;
+        const u32x4 q = qn;
+        const h2 sc = splat(sn_), zc = splat(zn_);
+        h2 qx[4];
+        if (TAIL && OUTL && has_next) {
+            const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + ((t + 1) * BK + h * 32 - kq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bn[j] = p[j];
         }
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             u32x4 (&cur)[4] = (mt & 1) ? fb : fa;
             u32x4 (&nxt)[4] = (mt & 1) ? fa : fb;
+            if (mt == 0) {                  // behind the first MFMA: everything it waits for (lgkmcnt(0): hipcc does not count
+                                            // across the loop edge) was issued before the barrier, not just now
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[0]), __builtin_bit_cast(h8, bc[0]),
+                                                               acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (mt < 7) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
-            } else if (MORE) {
+            } else if (has_next) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
+                if (!TAIL) fetch_b(slot_n2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = mt == 0 ? 1 : 0; j < 4; ++j)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
                                                                 acc[mt], 0, 0, 0);
-            if (MORE) {                     // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
+            if (!TAIL) {                    // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
                 if ((mt & 1) == 0) {
                     nib8_to_q(q[mt >> 1], qx);
                 } else {
@@ -650,14 +661,15 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    int slot_n = 1 % G3_BST;
-    auto bump = [&]() { slot_n = slot_n + 1 == G3_BST ? 0 : slot_n + 1; };
-    {   // qtiles >= 4 (launcher).  An odd count runs one leading k-tile and moves its B back to bA, so that the loop and the
-        // final pair keep static register roles; the last k-tile prepares nothing.
+    int slot_n2 = 2 % G3_BST;                  // weight slot of k-tile t + 2
+    auto bump = [&]() { slot_n2 = slot_n2 + 1 == G3_BST ? 0 : slot_n2 + 1; };
+    fetch_b(1 % G3_BST);
+    {   // qtiles >= 4 (launcher).  An odd count runs one leading k-tile and moves its B back to bA, so that the loop keeps
+        // static register roles; the loop leaves the last INT4 k-tile (its B in bB) to the tail.
         int t = 0;
         if (qtiles & 1) {
             sync_tile();
-            tile_body(std::true_type{}, 0, slot_n, bA, bB);
+            tile_body(std::false_type{}, 0, slot_n2, bA, bB);
             bump();
 #pragma unroll
             for (int j = 0; j < 4; ++j) bA[j] = bB[j];
@@ -665,42 +677,51 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         }
         for (; t + 2 < qtiles; t += 2) {
             sync_tile();
-            tile_body(std::true_type{}, t, slot_n, bA, bB);
+            tile_body(std::false_type{}, t, slot_n2, bA, bB);
             bump();
             sync_tile();
-            tile_body(std::true_type{}, t + 1, slot_n, bB, bA);
+            tile_body(std::false_type{}, t + 1, slot_n2, bB, bA);
             bump();
         }
         sync_tile();
-        tile_body(std::true_type{}, t, slot_n, bA, bB);
-        bump();
-        sync_tile();
-        tile_body(std::false_type{}, t + 1, slot_n, bB, bA);
-    }
-
-    // ---- fp16 outlier k-tiles (2 for r = 128): the pipeline is empty; A by DMA into stage 0, B fragments from oweight
-    if (OUTL) {
-        for (int t = qtiles; t < ktiles; ++t) {
-            __builtin_amdgcn_s_barrier();          // (loaders: every compute wave finished reading stage 0)
-            u32x4 bf[4];
-            const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + (t * BK + h * 32 - kq));
+        tile_body(std::false_type{}, t, slot_n2, bA, bB);
+        for (t = qtiles - 1; t < ktiles; ++t) {        // the last INT4 k-tile, then the outlier k-tiles
+            sync_tile();
+            tile_body(std::true_type{}, t, slot_n2, bB, bA);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = p[j];
-            __builtin_amdgcn_s_barrier();          // the loaders' pieces of this k-tile landed
-            asm volatile("" ::: "memory");
-            mma_tile(lds, bf);
+            for (int j = 0; j < 4; ++j) bB[j] = bA[j];
         }
     }
 
-    if (nok) {
+    // ---- epilogue: the fp16 tile goes through LDS (the activation ring is free now) so that the stores to y are whole 256-byte
+    // row segments, 16 bytes per lane: the direct form (2-byte stores, 64 bytes per row per instruction) cost ~10 us per block.
+    __builtin_amdgcn_s_barrier();              // every compute wave is done with the ring (the loader waves have exited)
+    asm volatile("" ::: "memory");
+    {
         const float bv = bias ? (float)bias[ncol] : 0.f;
+        uint8_t* const col = lds + nloc * 2;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = bm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < M) y[(size_t)m * N + ncol] = (f16)(acc[mt][e] + bv);
+            for (int e = 0; e < 16; ++e)
+                *(f16*)(col + (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * G3_YP) = (f16)(acc[mt][e] + bv);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const int ch = lane & 15, n0 = bn0 + ch * 8;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * 64 + i * 4 + (lane >> 4), m = bm0 + row;
+            if (m >= M || n0 >= N) continue;
+            const u32x4 v = *(const u32x4*)(lds + row * G3_YP + ch * 16);
+            f16* dst = y + (size_t)m * N + n0;
+            if (n0 + 8 <= N && (N & 7) == 0) *(u32x4*)dst = v;
+            else {
+                const h8 hv = __builtin_bit_cast(h8, v);
+                for (int j = 0; j < 8 && n0 + j < N; ++j) dst[j] = hv[j];
             }
+        }
     }
 }
 
@@ -751,6 +772,9 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                 return hipGetLastError();
             };
             g_last_variant = "gemm_v3_256x128";
+            static const int abl = getenv("QEFT_GEMM_ABL") ? atoi(getenv("QEFT_GEMM_ABL")) : 0;
+            if (abl == 1) return go3(gemm_w4_kernel_v3<true, 1>);
+            if (abl == 2) return go3(gemm_w4_kernel_v3<true, 2>);
             return outl ? go3(gemm_w4_kernel_v3<true>) : go3(gemm_w4_kernel_v3<false>);
         }
     }
