@@ -176,10 +176,19 @@ def hbm_traffic_per_gemv_launch(model_flag, bits):
 
 
 # ---------------------------------------------------------------------------------------------------- GEMM sub-records
-def _event_time_us(fn, reps, dev):
+def _event_time_us(fn, reps, dev, warm_ms=20.0):
+    """Steady-state time of fn() in us: the launches are timed after `warm_ms` of the same work.  A GPU coming out of idle
+    runs its first milliseconds at low clocks -- a 40-launch measurement straight after the operand set-up read 71 us for a
+    GEMM that runs 47-53 us per launch from the third millisecond on (profiles/r02_gemm_clock.txt)."""
+    import time
     import torch
     fn()
     torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < warm_ms:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(torch.cuda.current_stream(dev))
     for _ in range(reps):
@@ -189,7 +198,7 @@ def _event_time_us(fn, reps, dev):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def gemm_records(dev, m=2048, layers=4, reps=10):
+def gemm_records(dev, m=2048, layers=4, reps=25):
     """prefill_2048.per_shape and finetune_step: forward / dX / d(oweight) of the three 7B shapes at M = 2048, `layers`
     distinct weight sets cycled so that no launch finds its weights in L2, random (gaussian) activations."""
     import torch

@@ -474,6 +474,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // An LDS-DMA instruction holds its wave for 100-200 cycles at issue; in the compute waves' own stream (first version)
     // that stalled the matrix pipe 8 times per k-tile.  Loader waves absorb it in the shadow of their SIMD partner's MFMAs.
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const long long t_entry = ABL == 6 ? wall_clock64() : 0;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,11 +506,11 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
         const uint8_t* const sz_base = (const uint8_t*)(l == 0 ? scales : zeros);
         auto stage_a = [&](int t) {            // 8 DMA instructions
-            if (ABL == 1) return;
+            if (ABL == 1 || ABL >= 3) return;
             g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_A + (uint32_t)l * 8192u);
         };
         auto stage_b = [&](int t, int slot) {  // 2 (l < 2) or 1 DMA instructions
-            if (ABL == 1) return;
+            if (ABL == 1 || ABL >= 3) return;
             g3_dma16(qw + (size_t)t * 128, b_off, lds0 + G3_BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
             if (l < 2)
                 g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + G3_SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             } else {
                 wait_prev((t - 1) + LEAD < ktiles, (t - 1) + LEAD_B < qtiles);
             }
-            __builtin_amdgcn_s_barrier();      // k-tile t + 1 visible to everyone; everyone is done with k-tile t - 1
+            if (ABL < 3) __builtin_amdgcn_s_barrier();      // k-tile t + 1 visible to everyone; everyone is done with k-tile t - 1
             if (t + LEAD_B < qtiles) stage_b(t + LEAD_B, slot_f);      // BEFORE the activation pieces: see wait_prev
             if (t + LEAD < ktiles) stage_a(t + LEAD);
             slot_f = slot_f + 1 == G3_BST ? 0 : slot_f + 1;
@@ -588,6 +589,8 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         dequant_tile(0, bA);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fa[j] = *(const u32x4*)(lds + a_rd[j]);
+        if (ABL == 5)
+            for (int j = 0; j < 4; ++j) fb[j] = fa[j];
     }
 
     // One k-tile = 8 phases (one per 32-row m-tile), each: the fetch of the NEXT m-tile's fragments (the last phase fetches
@@ -633,7 +636,8 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                                                                acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (mt < 7) {
+            if (ABL == 5) {
+            } else if (mt < 7) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
             } else if (has_next) {
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             for (int j = mt == 0 ? 1 : 0; j < 4; ++j)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
                                                                 acc[mt], 0, 0, 0);
-            if (!TAIL) {                    // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
+            if (!TAIL && ABL != 4) {        // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
                 if ((mt & 1) == 0) {
                     nib8_to_q(q[mt >> 1], qx);
                 } else {
@@ -658,9 +662,11 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         }
     };
     auto sync_tile = [&]() {
-        __builtin_amdgcn_s_barrier();
+        if (ABL < 3) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    long long tk0 = 0, tr0 = 0;                // ABL 6: shader-clock / 100 MHz timestamps around the k loop -> the "bias" buffer
+    if (ABL == 6) { tk0 = clock64(); tr0 = wall_clock64(); }
     int slot_n2 = 2 % G3_BST;                  // weight slot of k-tile t + 2
     auto bump = [&]() { slot_n2 = slot_n2 + 1 == G3_BST ? 0 : slot_n2 + 1; };
     fetch_b(1 % G3_BST);
@@ -693,6 +699,13 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         }
     }
 
+    if (ABL == 6) {
+        const long long tk1 = clock64(), tr1 = wall_clock64();
+        if (wave == 0 && lane == 0 && bias) {
+            long long* d = (long long*)bias + (size_t)blockIdx.x * 8;
+            d[0] = tk1 - tk0; d[1] = tr1 - tr0; d[2] = tr0; d[3] = tr1; d[4] = t_entry;
+        }
+    }
     // ---- epilogue: the fp16 tile goes through LDS (the activation ring is free now) so that the stores to y are whole 256-byte
     // row segments, 16 bytes per lane: the direct form (2-byte stores, 64 bytes per row per instruction) cost ~10 us per block.
     __builtin_amdgcn_s_barrier();              // every compute wave is done with the ring (the loader waves have exited)
@@ -722,6 +735,10 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                 for (int j = 0; j < 8 && n0 + j < N; ++j) dst[j] = hv[j];
             }
         }
+    }
+    if (ABL == 6) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0 && lane == 0 && bias) ((long long*)bias)[(size_t)blockIdx.x * 8 + 5] = wall_clock64();
     }
 }
 
@@ -775,6 +792,10 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             static const int abl = getenv("QEFT_GEMM_ABL") ? atoi(getenv("QEFT_GEMM_ABL")) : 0;
             if (abl == 1) return go3(gemm_w4_kernel_v3<true, 1>);
             if (abl == 2) return go3(gemm_w4_kernel_v3<true, 2>);
+            if (abl == 3) return go3(gemm_w4_kernel_v3<true, 3>);
+            if (abl == 4) return go3(gemm_w4_kernel_v3<true, 4>);
+            if (abl == 5) return go3(gemm_w4_kernel_v3<true, 5>);
+            if (abl == 6) return go3(gemm_w4_kernel_v3<true, 6>);
             return outl ? go3(gemm_w4_kernel_v3<true>) : go3(gemm_w4_kernel_v3<false>);
         }
     }

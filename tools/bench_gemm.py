@@ -2,6 +2,7 @@
 import argparse
 import os
 import sys
+import time
 
 import torch
 
@@ -14,7 +15,8 @@ def main():
     ap.add_argument("--ms", default="2048,256,64,16")
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008")
     ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=25)
+    ap.add_argument("--warm-ms", type=float, default=20.0)
     ap.add_argument("--bwd", action="store_true")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -40,6 +42,11 @@ def main():
                         qeft_cuda.gemm_4bit_qeft(x, qw, sc, sz, ow)
             run()
             torch.cuda.synchronize()
+            t0 = time.perf_counter()               # steady state: a GPU coming out of idle runs its first ms at low clocks
+            while time.perf_counter() - t0 < a.warm_ms * 1e-3:
+                for _ in range(5):
+                    run()
+                torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.reps):

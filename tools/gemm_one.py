@@ -19,7 +19,7 @@ for i in range(4):
     ws.append((qw, sc, sz, ow))
 x = torch.randn(m, k, device=dev).half()
 dy = torch.randn(m, n, device=dev).half()
-for _ in range(5):
+for _ in range(int(os.environ.get("GEMM_ROUNDS", "5"))):      # x 4 weight sets; ~100 for steady-state clocks
     for qw, sc, sz, ow in ws:
         if bwd:
             qeft_cuda.gemm_4bit_dx(dy, qw, sc, sz, ow)
