@@ -1119,6 +1119,353 @@ __global__ __launch_bounds__(256) void gemm_w4_dx128_kernel(const f16* __restric
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// dX for the M >= 2048 tier (a fine-tune step): the forward v3 block turned around.  Block tile 256 (m) x 128 (k), n advances
+// 64 per tile; 4 compute waves (wave w: output columns 32 w .. 32 w + 31 of the tile, all 256 rows, 32 MFMAs per n-tile) and
+// 4 loader waves, one of each per SIMD.
+//   * dy tiles [256][64 n] ride a 4-stage LDS-DMA ring exactly like the forward's activations (same swizzle, same fragments).
+//   * the contraction index n is the packed layout's ROW index, so the B fragment of a lane is a column of the weight tile:
+//     the loader waves dequantise the tile [64 n][128 k] into LDS as fp16 (a lane owns one (n, 32-k chunk) = 16 packed
+//     bytes -> four 16-byte stores, 16-byte slots XOR-swizzled by n & 3 so that both the stores and the transposing reads
+//     are conflict-free) and the compute waves fetch their fragments with ds_read_b64_tr_b16 during the second half of the
+//     previous tile: two barriers per n-tile, A(t) "dy tile t + 1 landed / tile t - 1 released", B(t) "W tile t + 1 is in
+//     LDS".  The compute waves issue nothing but LDS reads and MFMAs.
+//   * the packed weights never touch LDS: each loader lane keeps a 4-deep ring of (16 packed bytes, scale, zero) in
+//     REGISTERS, loaded by inline-asm global loads that share the hand-counted vmcnt queue with the DMA pieces.
+//   * the block of the fp16 outlier k-tile (k >= K - n_out; n_out = 128 = one tile) runs the same pipeline with 64 fp16
+//     bytes per lane instead of 16 packed ones and no dequantisation -- it must not be the slow block of a one-wave grid.
+// ---------------------------------------------------------------------------------------------------
+constexpr int D3_BM = 256, D3_BK = 128, D3_BN = 64, D3_ST = 4;
+constexpr int D3_A = D3_BM * D3_BN * 2, D3_W = D3_BN * D3_BK * 2;        // 32 KB dy stage, 16 KB fp16 weight tile
+constexpr int D3_WOFF = D3_ST * D3_A;
+constexpr size_t D3_SMEM = (size_t)D3_WOFF + 2 * D3_W;                  // 163840 bytes: the whole LDS of a CU
+
+// The loader lanes' ring of weights in flight lives in ACCUMULATION registers named in the asm text (set S = a[8S .. 8S+5]:
+// 16 packed bytes, scale, zero).  The loads return long after the statement that issued them; a value hipcc could see would
+// be fair game for a register copy before the hand-placed s_waitcnt (it did exactly that at a switch: v_mov of registers
+// whose loads were still in flight) -- registers it never allocates cannot be copied.
+template <int S>
+__device__ __forceinline__ void d3_pload(uint32_t qoff, const void* qb, uint32_t soff, const void* sb, const void* zb);
+template <int S>
+__device__ __forceinline__ void d3_pread(u32x4& q, uint32_t& sv, uint32_t& zv);
+#define D3_RING_SET(S, A0, A1, A2, A3, A4, A5)                                                                                  \
+    template <>                                                                                                                 \
+    __device__ __forceinline__ void d3_pload<S>(uint32_t qoff, const void* qb, uint32_t soff, const void* sb, const void* zb) { \
+        asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, %1\n\tglobal_load_ushort a" #A4 ", %2, %3\n\t"               \
+                     "global_load_ushort a" #A5 ", %2, %4"                                                                      \
+                     :: "v"(qoff), "s"(qb), "v"(soff), "s"(sb), "s"(zb)                                                         \
+                     : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3, "a" #A4, "a" #A5);                                         \
+    }                                                                                                                           \
+    template <>                                                                                                                 \
+    __device__ __forceinline__ void d3_pread<S>(u32x4& q, uint32_t& sv, uint32_t& zv) {                                         \
+        uint32_t q0, q1, q2, q3;                                                                                                \
+        asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\t" \
+                     "v_accvgpr_read_b32 %3, a" #A3 "\n\tv_accvgpr_read_b32 %4, a" #A4 "\n\tv_accvgpr_read_b32 %5, a" #A5      \
+                     : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(sv), "=v"(zv) :: "memory");                                 \
+        q = u32x4{q0, q1, q2, q3};                                                                                              \
+    }
+D3_RING_SET(0, 0, 1, 2, 3, 4, 5)               // tuples start on even registers
+D3_RING_SET(1, 8, 9, 10, 11, 12, 13)
+D3_RING_SET(2, 16, 17, 18, 19, 20, 21)
+D3_RING_SET(3, 24, 25, 26, 27, 28, 29)
+#undef D3_RING_SET
+
+__global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
+                                                              const f16* __restrict__ scales, const f16* __restrict__ zeros,
+                                                              const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
+                                                              int K, int G, int n_out, int NB) {
+    extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through the k-tiles of one 256-row block of dy
+    const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
+    const int c = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
+    const int bm0 = (c / NB) * D3_BM, kt = c % NB;
+    const int ntiles = N / D3_BN;              // >= 4 (launcher)
+    const int kq = K - n_out;
+    const bool outl_blk = kt * D3_BK >= kq;    // n_out % 128 == 0: a k-tile is INT4 or fp16 as a whole
+
+    if (wave >= 4) {
+        // =========================================================== loader waves
+        const int l = wave - 4;
+        uint32_t a_off[8];         // dy piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (l * 8 + i) * 8 + (lane >> 3);
+            const int grow = min(bm0 + row, M - 1);
+            a_off[i] = (uint32_t)grow * (uint32_t)N * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+        auto stage_a = [&](int t) {
+            g3_dma_a8((const uint8_t*)dy + (size_t)t * (D3_BN * 2), a_off, lds0 + (uint32_t)(t & (D3_ST - 1)) * D3_A + (uint32_t)l * 8192u);
+        };
+        // weight role of the lane: row group 4 l + lane/16 of the tile's 16, piece p = lane % 16 of its 256 contiguous bytes
+        // = row n & 3 = (p & 7) >> 1, 32-k chunk kc = 2 (p >> 3) + (p & 1) of the 128-k tile
+        const int rgl = l * 4 + (lane >> 4), pp = lane & 15;
+        const int n_l = rgl * 4 + ((pp & 7) >> 1), n3 = n_l & 3, kc = 2 * (pp >> 3) + (pp & 1);
+        uint32_t w_dst[4];         // the lane's four 16-byte slots in the fp16 tile (+ buffer offset)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w_dst[j] = (uint32_t)(D3_WOFF + n_l * 256 + (((kc * 4 + j) ^ (n3 << 2) ^ n3) << 4));
+        auto sync = [&]() {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+
+        if (!outl_blk) {
+            const uint32_t q_off = (uint32_t)rgl * (uint32_t)K * 2u + (uint32_t)pp * 16u;
+            const uint32_t s_off = (uint32_t)n_l * 2u;
+            const size_t grp = (size_t)((kt * D3_BK) / G) * N;
+            // ring set S (tile i lives in set i % 4) <- the lane's 16 packed bytes, scale and zero of tile t: 3 vector-memory operations
+            auto pload = [&](auto set_tag, int t) {
+                t = min(t, ntiles - 1);            // past the end: a harmless reload, the queue depth stays the same
+                d3_pload<decltype(set_tag)::value>(q_off, qw + (size_t)t * 16 * K * 2 + (size_t)kt * 256, s_off,
+                                                   scales + grp + (size_t)t * D3_BN, zeros + grp + (size_t)t * D3_BN);
+            };
+            auto dequant_store = [&](auto set_tag, int buf) {
+                u32x4 q;
+                uint32_t sv, zv;
+                d3_pread<decltype(set_tag)::value>(q, sv, zv);
+                const h2 sc = splat(as_h2(sv)[0]), zc = splat(as_h2(zv)[0]);
+                u32x4 run[4];      // run j = the 8 consecutive k 8j .. 8j + 7 of the chunk
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    h2 wd[4];
+                    dequant8(q[w], sc, zc, wd);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) run[j][w] = as_u32(wd[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(u32x4*)(lds + w_dst[j] + buf * D3_W) = run[j];
+            };
+            // iteration t: [wait] A(t) [loads of tile t + 4, dy pieces of tile t + 3] [dequantise tile t + 1] B(t).
+            // In-order completion: the dy pieces of tile t + 1 were issued by iteration t - 2 (after that iteration's weight
+            // loads); younger than them is exactly iteration t - 1's 3 + 8 operations; the weights of tile t + 1 (iteration
+            // t - 3) are older still, so the one counted wait covers both.
+            using S0 = std::integral_constant<int, 0>;
+            using S1 = std::integral_constant<int, 1>;
+            using S2 = std::integral_constant<int, 2>;
+            using S3 = std::integral_constant<int, 3>;
+            auto steady = [&](int t, auto use, auto fill) {
+                asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                sync();
+                pload(fill, t + 4);
+                stage_a(t + 3);
+                dequant_store(use, (t + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sync();
+            };
+            // the last three tiles: nothing left to issue.  first: the step before it was a steady one (11 younger operations)
+            auto tail = [&](bool first, int t, auto use) {
+                if (first) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sync();
+                if (t + 1 < ntiles) dequant_store(use, (t + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sync();
+            };
+            pload(S0{}, 0); pload(S1{}, 1); pload(S2{}, 2); pload(S3{}, 3);
+            stage_a(0); stage_a(1); stage_a(2);
+            asm volatile("s_waitcnt vmcnt(33)" ::: "memory");            // tile 0's weights: 9 + 24 younger
+            dequant_store(S0{}, 0);
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // dy tile 0
+            sync();
+            // t = 0: dy tile 1 landed <=> all but tile 2's 8 pieces
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            sync();
+            pload(S0{}, 4);
+            stage_a(3);
+            dequant_store(S1{}, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            sync();
+            // steady steps t = 1 .. ntiles - 4 (groups of four, then 0..3 more), tail steps ntiles - 3 .. ntiles - 1
+            int t = 1;
+            for (; t + 7 <= ntiles; t += 4) {
+                steady(t, S2{}, S1{});
+                steady(t + 1, S3{}, S2{});
+                steady(t + 2, S0{}, S3{});
+                steady(t + 3, S1{}, S0{});
+            }
+            switch (ntiles - 3 - t) {
+                case 0: tail(true, t, S2{}); tail(false, t + 1, S3{}); tail(false, t + 2, S0{}); break;
+                case 1: steady(t, S2{}, S1{}); tail(true, t + 1, S3{}); tail(false, t + 2, S0{}); tail(false, t + 3, S1{}); break;
+                case 2: steady(t, S2{}, S1{}); steady(t + 1, S3{}, S2{}); tail(true, t + 2, S0{}); tail(false, t + 3, S1{});
+                        tail(false, t + 4, S2{}); break;
+                default: steady(t, S2{}, S1{}); steady(t + 1, S3{}, S2{}); steady(t + 2, S0{}, S3{});
+                         tail(true, t + 3, S1{}); tail(false, t + 4, S2{}); tail(false, t + 5, S3{}); break;
+            }
+        } else {
+            // fp16 outlier k-tile: no dequantisation, so the weight tile goes straight into its LDS buffer by DMA (the
+            // swizzle is applied on the SOURCE side: destination lane-linear, 4 rows of 256 B per instruction).  Buffer
+            // (t + 2) & 1 is free from A(t) on (the compute waves fetched tile t's fragments during tile t - 1), which gives
+            // the DMA 1.5 tiles until B(t + 1); a one-dword touch of every 64 bytes six tiles ahead pulls the rows into L2
+            // so that 1.5 tiles suffice.  iteration t: [wait] A(t) [touch t + 6, W tile t + 2, dy tile t + 3] [wait] B(t).
+            const uint8_t* const obase = (const uint8_t*)ow + (size_t)(kt * D3_BK - kq) * 2;
+            const size_t tile_stride = (size_t)D3_BN * n_out * 2;
+            uint32_t o_off[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * l + 4 * i + (lane >> 4), r3 = (lane >> 4) & 3;
+                o_off[i] = (uint32_t)row * (uint32_t)n_out * 2u + (uint32_t)(((lane & 15) ^ (r3 << 2) ^ r3) << 4);
+            }
+            const uint32_t pf_off = (uint32_t)(16 * l + (lane >> 2)) * (uint32_t)n_out * 2u + (uint32_t)(lane & 3) * 64u;
+            auto touch = [&](int t) {              // 1 operation
+                t = min(t, ntiles - 1);
+                asm volatile("global_load_dword a30, %0, %1" :: "v"(pf_off), "s"(obase + (size_t)t * tile_stride) : "memory", "a30");
+            };
+            auto stage_w = [&](int t) {            // 4 DMA operations
+                const uint8_t* b = obase + (size_t)t * tile_stride;
+                const uint32_t dst = lds0 + D3_WOFF + (uint32_t)(t & 1) * D3_W + (uint32_t)l * 4096u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g3_dma16(b, o_off[i], dst + i * 1024);
+            };
+            for (int t = 0; t < 6; ++t) touch(t);
+            stage_w(0); stage_w(1);
+            stage_a(0); stage_a(1); stage_a(2);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // dy tile 0 (and, older, both W tiles)
+            sync();
+            for (int t = 0; t < ntiles; ++t) {
+                // dy tile t + 1: issued by iteration t - 1... no, t - 2 (or the prologue); younger = iteration t - 1's 13 operations
+                if (t == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sync();
+                const bool full = t + 3 < ntiles;
+                if (full) {
+                    touch(t + 6);
+                    stage_w(t + 2);
+                    stage_a(t + 3);
+                    // W tile t + 1: issued by iteration t - 1 ahead of its 8 dy pieces; + this iteration's 13
+                    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+                } else {
+                    if (t + 2 < ntiles) stage_w(t + 2);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                sync();
+            }
+        }
+        return;
+    }
+
+    // =============================================================== compute waves
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // dy fragment of m-tile mt, n-step j: the 8 consecutive n  32 h + 8 j .. + 7  of row r (chunk 4 h + j, swizzled)
+    uint32_t a_rd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_rd[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));
+    // W fragment of n-step j: rows 32 h + 8 j + {0..3} and + {4..7} of column 32 wave + r, by two transposing reads: lane
+    // 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of the group's 16 (qeft lds_read_tr8 note above)
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const int tq = (lane & 15) >> 2;
+    const int tslot = wave * 4 + ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    const uint32_t w_rd = (uint32_t)(D3_WOFF + (32 * h + tq) * 256 + ((tslot ^ (tq << 2) ^ tq) << 4) + (lane & 1) * 8);
+    auto tr_read = [&](uint32_t off) -> u32x2 {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lds0 + off)));
+    };
+    auto fetch_w = [&](int buf, int j, u32x4& dst) {
+        const u32x2 lo = tr_read(w_rd + buf * D3_W + (8 * j) * 256), hi = tr_read(w_rd + buf * D3_W + (8 * j + 4) * 256);
+        dst = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+
+    u32x4 bA[4], bB[4];        // W fragments of the even / odd n-tiles
+    u32x4 fa[4], fb[4];        // dy fragments, two m-tiles in rotation
+    __builtin_amdgcn_s_barrier();              // dy tile 0 and W tile 0 are in LDS
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fetch_w(0, j, bA[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[j] = *(const u32x4*)(lds + a_rd[j]);
+
+    // One n-tile = 8 phases (one per 32-row m-tile): the fetch of the next m-tile's dy fragments a whole phase ahead (as in
+    // the forward kernel), 4 MFMAs, and in phases 4..7 (behind barrier B) one n-step of the next tile's W fragments.
+    auto tile_body = [&](auto next_tag, int t, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
+        constexpr bool NEXT = decltype(next_tag)::value;
+        const uint8_t* st = lds + (size_t)(t & (D3_ST - 1)) * D3_A;
+        const uint8_t* sn = lds + (size_t)((t + 1) & (D3_ST - 1)) * D3_A;
+        const int nbuf = (t + 1) & 1;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            u32x4 (&cur)[4] = (mt & 1) ? fb : fa;
+            u32x4 (&nxt)[4] = (mt & 1) ? fa : fb;
+            if (mt == 0) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[0]), __builtin_bit_cast(h8, bc[0]),
+                                                               acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (mt == 4) {
+                __builtin_amdgcn_s_barrier();              // B(t): W tile t + 1 is in LDS
+                asm volatile("" ::: "memory");
+            }
+            if (mt < 7) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
+            } else if (NEXT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
+            }
+            if (NEXT && mt >= 4) fetch_w(nbuf, mt - 4, bn[mt - 4]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = mt == 0 ? 1 : 0; j < 4; ++j)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
+                                                                acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto sync_tile = [&]() {
+        __builtin_amdgcn_s_barrier();              // A(t)
+        asm volatile("" ::: "memory");
+    };
+    {
+        int t = 0;
+        if (ntiles & 1) {
+            sync_tile();
+            tile_body(std::true_type{}, 0, bA, bB);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bA[j] = bB[j];
+            t = 1;
+        }
+        for (; t + 2 < ntiles; t += 2) {
+            sync_tile();
+            tile_body(std::true_type{}, t, bA, bB);
+            sync_tile();
+            tile_body(std::true_type{}, t + 1, bB, bA);
+        }
+        sync_tile();
+        tile_body(std::true_type{}, t, bA, bB);
+        sync_tile();
+        tile_body(std::false_type{}, t + 1, bB, bA);
+    }
+
+    // ---- epilogue: as the forward kernel's -- the fp16 tile goes through LDS (the dy ring is free), 16-byte stores of whole rows
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        uint8_t* const col = lds + (wave * 32 + r) * 2;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                *(f16*)(col + (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * G3_YP) = (f16)acc[mt][e];
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const int ch = lane & 15;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int row = wave * 64 + i * 4 + (lane >> 4), m = bm0 + row;
+            if (m >= M) continue;
+            *(u32x4*)(dx + (size_t)m * K + kt * D3_BK + ch * 8) = *(const u32x4*)(lds + row * G3_YP + ch * 16);
+        }
+    }
+}
+
 // Split factor of the contraction (n) for dX: only when the 128 x 64 tiling gives too few blocks to hide the latency of
 // a long n loop.
 int gemm_w4_dx_split(int M, int N, int K) {
@@ -1133,6 +1480,25 @@ int gemm_w4_dx_split(int M, int N, int K) {
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace,
                              size_t workspace_bytes) {
+    // 256 x 128 tiles with loader waves (gemm_w4_dx_kernel_v3) when they give (nearly) every CU a block: the M >= 2048 tier
+    // of a fine-tune step.  QEFT_DX_V3 = 0 / 1 forces the choice (A/B).
+    {
+        static const int force_v3 = getenv("QEFT_DX_V3") ? atoi(getenv("QEFT_DX_V3")) : -1;
+        const int mb = (M + D3_BM - 1) / D3_BM, kb = K / D3_BK;
+        const bool outl = ow && n_out > 0;
+        const bool ok3 = K % D3_BK == 0 && (!outl || n_out % D3_BK == 0) && G % D3_BK == 0 && N % D3_BN == 0 && N >= 4 * D3_BN &&
+                         (size_t)M * N * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32) &&
+                         (size_t)N * (outl ? n_out : 0) * 2 < (1ull << 32);
+        if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * kb >= 224 && M >= 1024))) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_dx_kernel_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D3_SMEM);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(gemm_w4_dx_kernel_v3, dim3(mb * kb), dim3(512), D3_SMEM, st, (const f16*)dy, (const uint8_t*)qw,
+                               (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (f16*)dx, M, N, K, G,
+                               outl ? n_out : 0, kb);
+            g_last_variant = "dx256";
+            return hipGetLastError();
+        }
+    }
     // the 128-wide tile when it still gives every CU two blocks; smaller problems keep the 64-wide tile (twice the
     // blocks, and a split over n below 512 of them)
     if (K % 128 == 0 && n_out % 32 == 0 && ((M + DX_BM - 1) / DX_BM) * (K / 128) >= 512) {

@@ -130,3 +130,22 @@ def test_gemm_large_m_tile_edges(m, n, k, r, g):
     yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None,
                           bufs["bias"], g).astype(np.float64)
     assert rel_err(y.cpu().numpy(), yref) < REL_TOL
+
+
+@pytest.mark.parametrize("m,n,k,r,g", [(1100, 256, 6144, 128, 128), (1100, 320, 6144, 0, 256), (1280, 384, 6144, 128, 6144),
+                                       (1100, 448, 6144, 128, 128), (1025, 512, 6144, 0, 128), (1100, 704, 6144, 128, 128)])
+def test_dx_large_m_tile_edges(m, n, k, r, g):
+    """The 256 x 128 tile of dX with everything ragged: M not a multiple of 256, every remainder of the n-tile count modulo the
+    loader's 4-deep weight ring (4, 5, 6, 7, 8, 11 n-tiles), no outlier slice, group 256 and per-channel -- full output vs oracle."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=m + n)
+    t = layer_to_torch(bufs, DEV)
+    dy = (np.random.default_rng(n).standard_normal((m, n)) * 0.1).astype(np.float16)
+    dx = qeft_cuda.gemm_4bit_dx(torch.from_numpy(dy).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                t.get("oweight") if r else None)
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == "dx256", variant
+    w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None, g)
+    ref = dy.astype(np.float64) @ w.astype(np.float64)
+    assert rel_err(dx.cpu().numpy(), ref) < REL_TOL
