@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
 #pragma unroll
                 for (int j = 0; j < 4; ++j) *(u32x4*)(lds + w_dst[j] + buf * D3_W) = run[j];
             };
-            // iteration t: [wait] A(t) [loads of tile t + 4, dy pieces of tile t + 3] [dequantise tile t + 1] B(t).
+            // iteration t: [wait] A(t) [loads of tile t + 4] [dequantise tile t + 1] B(t) [dy pieces of tile t + 3].
             // In-order completion: the dy pieces of tile t + 1 were issued by iteration t - 2 (after that iteration's weight
             // loads); younger than them is exactly iteration t - 1's 3 + 8 operations; the weights of tile t + 1 (iteration
             // t - 3) are older still, so the one counted wait covers both.
@@ -1249,10 +1249,11 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
                 asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
                 sync();
                 pload(fill, t + 4);
-                stage_a(t + 3);
                 dequant_store(use, (t + 1) & 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 sync();
+                stage_a(t + 3);        // behind B(t): a DMA instruction holds the wave 100-200 cycles at issue, and the compute
+                                       // waves reach B(t) after half a tile (~500 cycles)
             };
             // the last three tiles: nothing left to issue.  first: the step before it was a steady one (11 younger operations)
             auto tail = [&](bool first, int t, auto use) {
@@ -1273,10 +1274,10 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             sync();
             pload(S0{}, 4);
-            stage_a(3);
             dequant_store(S1{}, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             sync();
+            stage_a(3);
             // steady steps t = 1 .. ntiles - 4 (groups of four, then 0..3 more), tail steps ntiles - 3 .. ntiles - 1
             int t = 1;
             for (; t + 7 <= ntiles; t += 4) {
@@ -1297,8 +1298,8 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             // fp16 outlier k-tile: no dequantisation, so the weight tile goes straight into its LDS buffer by DMA (the
             // swizzle is applied on the SOURCE side: destination lane-linear, 4 rows of 256 B per instruction).  Buffer
             // (t + 2) & 1 is free from A(t) on (the compute waves fetched tile t's fragments during tile t - 1), which gives
-            // the DMA 1.5 tiles until B(t + 1); a one-dword touch of every 64 bytes six tiles ahead pulls the rows into L2
-            // so that 1.5 tiles suffice.  iteration t: [wait] A(t) [touch t + 6, W tile t + 2, dy tile t + 3] [wait] B(t).
+            // the DMA one tile (B(t) .. B(t + 1)); a one-dword touch of every 64 bytes six tiles ahead pulls the rows into L2
+            // so that one tile suffices.  iteration t: [wait] A(t) [wait] B(t) [touch t + 6, W tile t + 2, dy tile t + 3].
             const uint8_t* const obase = (const uint8_t*)ow + (size_t)(kt * D3_BK - kq) * 2;
             const size_t tile_stride = (size_t)D3_BN * n_out * 2;
             uint32_t o_off[4];
@@ -1324,23 +1325,22 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // dy tile 0 (and, older, both W tiles)
             sync();
             for (int t = 0; t < ntiles; ++t) {
-                // dy tile t + 1: issued by iteration t - 1... no, t - 2 (or the prologue); younger = iteration t - 1's 13 operations
+                // dy tile t + 1: issued by iteration t - 2 (or the prologue); younger = iteration t - 1's 13 operations
                 if (t == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 sync();
-                const bool full = t + 3 < ntiles;
-                if (full) {
+                // W tile t + 1: issued by iteration t - 1 ahead of its 8 dy pieces
+                if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                sync();
+                if (t + 3 < ntiles) {          // behind B(t), like the INT4 path's DMA
                     touch(t + 6);
                     stage_w(t + 2);
                     stage_a(t + 3);
-                    // W tile t + 1: issued by iteration t - 1 ahead of its 8 dy pieces; + this iteration's 13
-                    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-                } else {
-                    if (t + 2 < ntiles) stage_w(t + 2);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (t + 2 < ntiles) {
+                    stage_w(t + 2);
                 }
-                sync();
             }
         }
         return;
