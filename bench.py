@@ -348,7 +348,7 @@ def main():
             roof["traffic_note"] = (f"FETCH_SIZE x 1024 x 2 (gfx950 correction), mean over {traffic['launches_sampled']} "
                                     "GEMV launches of a separate `rocprofv3 --pmc FETCH_SIZE --kernel-trace` child run")
         # the same, one GEMV of the layer at a time (32 launches per replay): per-kernel rates for DESIGN.md / rocprof
-        if g2 is not None and world == 1 and not args.no_per_kind:
+        if g2 is not None and world == 1 and not eng.tp and not args.no_per_kind:
             per = {}
             lin0 = eng.lin[0]
             parts = {"qkv": ("q", "k", "v"), "o": ("o",), "gu": ("g", "u"), "d": ("d",)}

@@ -71,3 +71,35 @@ def pair_interleave(gate, up):
     if gate.bias is not None:
         bias = torch.cat([gate.bias.view(n // 8, 8), up.bias.view(n // 8, 8)], 1).reshape(2 * n)
     return _operand(qw, szp, ow, bias, 2 * n, k, g, r)
+
+
+def column_shard(layer, owned_cols):
+    """The K-shard of `layer` for a tensor-parallel rank that owns the input columns `owned_cols` (kernel column order, i.e.
+    after the layer's reorder; any order, typically a contiguous run of INT4 columns plus some of the fp16 outlier columns).
+
+    Returns (operand, local_pos): the operand keeps every output row and, of the input columns, the whole 128-column groups
+    that hold an owned INT4 column plus the complete fp16 outlier slice; local_pos[i] is where owned column i sits in the
+    operand's x vector.  x positions of columns the rank does NOT own (the rest of a boundary group, foreign outlier
+    columns) must hold zeros: every column is then counted exactly once in the sum of the ranks' partial outputs, which is
+    what the all-reduce after o_proj / down_proj forms (Megatron pairing: the row-sharded producer feeds the column-sharded
+    consumer with no collective in between).  A boundary group's weights are streamed by both neighbours (<= 2 groups of
+    K / P per rank) and the outlier slice by every rank (N x 128 fp16)."""
+    from . import qeft_cuda
+    k, g, r = _check([layer])
+    assert g == 128 and r in (0, 128), "column sharding cuts at the 128-column groups of the v3 GEMV"
+    n, kq = layer.outfeatures, k - r
+    owned = torch.as_tensor(owned_cols, dtype=torch.long, device=layer.qweight.device)
+    q_cols = owned[owned < kq]
+    g0, g1 = (int(q_cols.min()) // 128, int(q_cols.max()) // 128 + 1) if q_cols.numel() else (0, 0)
+    if g1 == g0 and r == 0:
+        g1 = g0 + 1                    # an operand needs at least one step
+    kp_q = 128 * (g1 - g0)
+    qw = torch.cat([layer.qweight[:, 128 * g0:128 * g1], layer.qweight[:, kq:]], 1)
+    sc = torch.cat([layer.scales[g0:g1], layer.scales[kq // g:]], 0).contiguous()
+    sz = torch.cat([layer.scaled_zeros[g0:g1], layer.scaled_zeros[kq // g:]], 0).contiguous()
+    szp = qeft_cuda.pack_scales(sc, sz, n, kp_q + r, g) if sc.is_cuda else None
+    op = SimpleNamespace(qweight=qw.contiguous(), sz_packed=szp, scales=sc, scaled_zeros=sz,
+                         oweight=_plain_oweight(layer).contiguous() if r else None, bias=None,
+                         outfeatures=n, infeatures=kp_q + r, group_size=g, outlierfeatures=r, first_group=g0)
+    local = torch.where(owned < kq, owned - 128 * g0, kp_q + owned - kq).to(torch.int32)
+    return op, local

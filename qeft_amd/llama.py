@@ -257,10 +257,13 @@ def _ptr_array(tensors):
 class DecodeEngine:
     """One decode token = a fixed list of C-ABI launches on static buffers (hipGraph-capturable).
 
-    With `tp_group` (world size P > 1) every quantized linear is row-sharded over the group (sharded.py): each rank
-    streams 1/P of the weights and an all-gather rebuilds the activation the next linear needs (4 per layer: attention
-    output, o_proj, silu(gate)*up, down_proj).  q|k|v needs none: a rank owns the rows of its own heads, so attention
-    and the KV caches are sharded by heads as well; norms, embedding and lm_head are replicated.
+    With `tp_group` (world size P > 1) the quantized linears are sharded over the group in Megatron pairs: q|k|v and
+    gate|up by output rows (a rank owns the rows of its own heads / its slice of the MLP width, so attention, the KV caches
+    and SiLU stay local), o_proj and down_proj by input columns (fuse.column_shard), so that a row-sharded producer feeds
+    its column-sharded consumer without a collective; the partial outputs (+ the fp32 residual on rank 0) are summed by ONE
+    fp32 all-reduce of `hidden` floats after o_proj and one after down_proj: 2 collectives per layer (16 KB each for 7B;
+    xGMI latency-bound).  Norms, embedding and lm_head are replicated.  Layers the v3 GEMV does not take (3-bit, odd
+    shapes) keep the round-1 scheme: every linear row-sharded, 4 all-gathers per layer.
     """
 
     def __init__(self, model: QuantLlama, use_graph=True, tp_group=None):
@@ -275,7 +278,8 @@ class DecodeEngine:
         self.bits = getattr(s, "bits", 4)
         # tp_group: a torch.distributed group (RCCL), or any object with .world, .rank and .all_gather(out, inp) -- the
         # tests drive two ranks of one process in lock step through such an object (tests/test_gpu_tp.py)
-        self.sim_group = tp_group if hasattr(tp_group, "all_gather") else None
+        self.sim_group = tp_group if hasattr(tp_group, "all_gather") or hasattr(tp_group, "all_reduce") else None
+        self.n_collectives = 0              # collectives issued by the last eager _launch_token (tests: 2 per layer)
         if self.sim_group is not None:
             self.P, self.rank = tp_group.world, tp_group.rank
         else:
@@ -333,6 +337,16 @@ class DecodeEngine:
         g_, k_ok = s.group_size, (s.hidden % 128 == 0 and s.inter % 128 == 0)
         self.v3 = (self.bits == 4 and not tp and k_ok and s.n_out in (0, 128) and g_ == 128 and s.hidden % 16 == 0
                    and s.inter % 16 == 0 and kvd % 16 == 0 and os.environ.get("QEFT_ENGINE_V2") != "1")
+        self.tp3 = (tp and self.bits == 4 and k_ok and s.n_out in (0, 128) and g_ == 128 and self.hs % 16 == 0
+                    and self.kvs % 16 == 0 and self.its % 16 == 0 and self.its >= 128
+                    and os.environ.get("QEFT_ENGINE_V2") != "1")
+        if self.tp3:
+            self.h32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)
+            self.part32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)    # partial o_proj / down_proj output -> all-reduce
+            self.zero32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)    # the "residual" of ranks > 0
+            self.n_ssq_tb = self.lib.qeft_token_begin_norm_blocks(s.hidden)
+            self.ssq = torch.zeros((self.n_ssq_tb + 3) // 4 * 4, dtype=torch.float32, device=dev)
+            self.tp3ops = []
         if self.v3:
             self.h32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)
             self.n_ssq_tb = self.lib.qeft_token_begin_norm_blocks(s.hidden)
@@ -348,6 +362,9 @@ class DecodeEngine:
         for L in model.model.layers:
             a, mlp = L.self_attn, L.mlp
             names = dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.o_proj, g=mlp.gate_proj, u=mlp.up_proj, d=mlp.down_proj)
+            if self.tp3:
+                self.tp3ops.append(self._build_tp3_layer(names))
+                continue
             if tp:
                 names = {kk: shard_quantlinear(vv, self.rank, P).to(dev) for kk, vv in names.items()}
             self.lin.append(names)
@@ -387,7 +404,40 @@ class DecodeEngine:
     def h(self):
         return self.hbuf[0]
 
+    def _build_tp3_layer(self, names):
+        """Operands of one decoder layer for this rank (Megatron pairing, fuse.py): row shards of q|k|v and gate|up, column
+        shards of o_proj and down_proj with their zero-initialised x vectors (only owned positions are ever written)."""
+        from . import fuse
+        from .sharded import shard_quantlinear
+        s, P, rk, dev = self.m.shape, self.P, self.rank, self.dev
+        row = {kk: shard_quantlinear(names[kk], rk, P).to(dev) for kk in ("q", "k", "v", "g", "u")}
+        o, d = names["o"], names["d"]
+        if hasattr(o, "reorder_ids"):                   # natural index -> o_proj's column (outliers last)
+            inv = torch.empty_like(o.reorder_ids)
+            inv[o.reorder_ids] = torch.arange(o.reorder_ids.numel(), device=inv.device)
+        else:
+            inv = torch.arange(s.hidden, device=dev)
+        o_op, att_pos = fuse.column_shard(o, inv[rk * self.hs:(rk + 1) * self.hs])
+        d_op, d_pos = fuse.column_shard(d, torch.arange(rk * self.its, (rk + 1) * self.its, device=dev))
+        lead = int(d_pos[0])
+        assert torch.equal(d_pos.long(), lead + torch.arange(self.its, device=d_pos.device)), \
+            "down_proj's owned columns must be one run of its x vector (outlier columns last, owned by the last rank)"
+        f16 = dict(dtype=torch.float16, device=dev)
+        return dict(qkv=fuse.concat_linears([row["q"], row["k"], row["v"]]), o=o_op, gu=fuse.pair_interleave(row["g"], row["u"]),
+                    d=d_op, x_o=torch.zeros(o_op.infeatures, **f16), att_pos=att_pos.to(dev).contiguous(),
+                    x_d=torch.zeros(d_op.infeatures, **f16), lead_d=lead)
+
+    def _all_reduce(self, t):
+        """In-place sum over the tensor-parallel group (fp32 partial outputs; RCCL ring over xGMI, or the tests' stand-in)."""
+        self.n_collectives += 1
+        if self.sim_group is not None:
+            self.sim_group.all_reduce(t)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.tp_group)
+
     def _all_gather(self, out, inp):
+        self.n_collectives += 1
         if self.sim_group is not None:
             self.sim_group.all_gather(out, inp)
         else:
@@ -413,13 +463,19 @@ class DecodeEngine:
         """The kernel(s) behind the quantized linears of a token (for bench.py's roofline record)."""
         if self.bits == 3:
             return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel <BITS = 3>"
-        if self.v3:
+        if self.v3 or self.tp3:
             return "qeft::gemv_v3_kernel"
         return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel"
 
     def weight_bytes_per_token(self):
         """Algorithmic HBM bytes of the quantized linears one token streams on THIS rank (SURVEY.md §8d formula)."""
         tot = 0
+        if self.tp3:        # the operands as sharded: whole boundary groups and the full outlier slice count (they are streamed)
+            for ops in self.tp3ops:
+                for op in (ops["qkv"], ops["o"], ops["gu"], ops["d"]):
+                    n, k, r, g = op.outfeatures, op.infeatures, op.outlierfeatures, op.group_size
+                    tot += n * (k - r) // 2 + 2 * (k // g) * n * 2 + n * r * 2 + 2 * k + 2 * n
+            return tot
         for names in self.lin:
             for l in names.values():
                 n, k, r, g = l.outfeatures, l.infeatures, l.outlierfeatures, l.group_size
@@ -431,8 +487,11 @@ class DecodeEngine:
     def _launch_token(self, linears_only=False, only=None):
         """only (with linears_only): launch just one GEMV of every layer -- "qkv", "o", "gu" or "d" -- for per-kernel timing."""
         import torch.distributed as dist
+        self.n_collectives = 0
         if self.v3:
             return self._launch_token_v3(linears_only, only)
+        if self.tp3:
+            return self._launch_token_tp3(linears_only, only)
         s, lib, ck, P, tp = self.m.shape, self.lib, _lib.check, self.P, self.tp
         w3 = self.bits == 3
         gemv_group = lib.qeft_gemv_w3_group if w3 else lib.qeft_gemv_w4_group
@@ -576,6 +635,58 @@ class DecodeEngine:
             ck(pick("gu")(pk["gu"], xn, self.act.data_ptr(), mode=1, ssq_in=ssq, n_ssq=n_ssq))
             nxt = layers[li + 1].input_layernorm.data_ptr() if li + 1 < len(layers) else None
             ck(pick("d")(pk["d"], self.act.data_ptr(), h32, residual=h32, gamma_out=nxt))
+        if linears_only:
+            return
+        ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, eps, st))
+        torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
+        ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
+                              1 if self.greedy else 0, st))
+
+    @torch.no_grad()
+    def _launch_token_tp3(self, linears_only=False, only=None):
+        """One token of one tensor-parallel rank on the v3 GEMV: q|k|v -> attention (local heads, output scattered into
+        o_proj's x vector) -> o_proj partial (+ h32 on rank 0) -> all-reduce -> residual_norm -> gate|up (SiLU epilogue, output
+        straight into down_proj's x vector) -> down_proj partial (+ h32 on rank 0) -> all-reduce -> residual_norm."""
+        s, lib, ck = self.m.shape, self.lib, _lib.check
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        g, no, eps = s.group_size, s.n_out, s.rms_eps
+        layers = self.m.model.layers
+        xn, ssq, h32, part = self.xn.data_ptr(), self.ssq.data_ptr(), self.h32.data_ptr(), self.part32.data_ptr()
+        res_in = h32 if self.rank == 0 else self.zero32.data_ptr()
+        n_ssq = self.n_ssq_tb
+
+        def lin(op, x, y, mode=0, residual=None, ssq_in=None):
+            return lib.qeft_decode_linear(x, op.qweight.data_ptr(), op.sz_packed.data_ptr(),
+                                          op.oweight.data_ptr() if no else None, None, y, op.outfeatures, op.infeatures, g, no,
+                                          mode, residual, ssq_in, n_ssq if ssq_in else 0, eps, None, None, None, st)
+
+        def pick(tag):
+            return lin if only in (None, tag) else (lambda *a, **kw: 0)
+        if not linears_only:
+            ck(lib.qeft_token_begin_norm(self.m.model.embed_tokens.weight.data_ptr(), self.tok.data_ptr(),
+                                         self.rope_tab.data_ptr(), self.pos.data_ptr(), h32, self.rope_row.data_ptr(),
+                                         layers[0].input_layernorm.data_ptr(), xn, ssq, s.hidden, s.vocab, s.max_seq, st))
+        qp = self.qkv_loc.data_ptr()
+        for li, L in enumerate(layers):
+            pk = self.tp3ops[li]
+            ck(pick("qkv")(pk["qkv"], xn, qp, ssq_in=ssq))
+            if not linears_only:
+                ck(lib.qeft_rope_attn_decode(qp, qp + self.hs * 2, qp + (self.hs + self.kvs) * 2,
+                                             self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
+                                             self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                             pk["att_pos"].data_ptr(), pk["x_o"].data_ptr(),
+                                             self.attn_ws.data_ptr() if self.attn_ws is not None else None,
+                                             self.attn_split, self.heads_l, self.kv_heads_l, s.max_seq, st))
+            ck(pick("o")(pk["o"], pk["x_o"].data_ptr(), part, residual=res_in))
+            if not linears_only:
+                self._all_reduce(self.part32)
+                ck(lib.qeft_residual_norm(part, None, L.post_attention_layernorm.data_ptr(), h32, xn, ssq, s.hidden, st))
+            ck(pick("gu")(pk["gu"], xn, pk["x_d"].data_ptr() + pk["lead_d"] * 2, mode=1, ssq_in=ssq))
+            ck(pick("d")(pk["d"], pk["x_d"].data_ptr(), part, residual=res_in))
+            if not linears_only:
+                self._all_reduce(self.part32)
+                nxt = layers[li + 1].input_layernorm.data_ptr() if li + 1 < len(layers) else None
+                ck(lib.qeft_residual_norm(part, None, nxt, h32, xn if nxt else None, ssq if nxt else None, s.hidden, st))
         if linears_only:
             return
         ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, eps, st))

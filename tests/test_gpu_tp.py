@@ -1,6 +1,9 @@
-"""Row-sharded decode engine on the real collective library (RCCL): a group of ONE rank runs exactly the launch
-sequence of the multi-GPU bench (sharded linears, one all-gather per linear, hipGraph capture of the collectives) and
-must reproduce the single-GPU engine bit for bit.  Ranks > 1 are covered on CPU (gloo) in test_sharded_cpu.py."""
+"""Tensor-parallel decode engine (Megatron pairing: q|k|v and gate|up by rows, o_proj and down_proj by columns, one fp32
+all-reduce after each of the two, llama.py).  On the real collective library (RCCL) a group of ONE rank runs exactly the
+launch sequence of the multi-GPU bench, hipGraph capture of the collectives included; ranks > 1 run as threads of one
+process in lock step on the one GPU.  The sharded sum adds the K shards' fp32 partial outputs in rank order, so results
+equal the single-GPU engine to rounding, not bit for bit: the tolerance below is 2e-3 of the largest logit.  The sharding
+arithmetic alone is covered on CPU with gloo (tests/test_tp_shards_cpu.py)."""
 import os
 import socket
 
@@ -36,10 +39,13 @@ def test_tp_engine_group_of_one_equals_single_gpu_engine(world_of_one, use_graph
     tokens = torch.randint(0, shape.vocab, (12,), generator=torch.Generator().manual_seed(1))
     ref = DecodeEngine(model, use_graph=use_graph).teacher_forced_logits(tokens)
     eng = DecodeEngine(model, use_graph=use_graph, tp_group=world_of_one)
-    assert eng.tp and eng.P == 1
+    assert eng.tp and eng.P == 1 and eng.tp3
     got = eng.teacher_forced_logits(tokens)
     assert torch.isfinite(got).all()
-    assert torch.equal(got, ref)
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
+    if not use_graph:
+        assert eng.n_collectives == 2 * shape.n_layers          # one all-reduce after o_proj, one after down_proj
 
 
 def test_sharded_quantlinear_on_rccl(world_of_one):
@@ -78,6 +84,13 @@ class _LockstepGroup:
                 self.barrier.wait()
                 out.view(self.world, -1).copy_(torch.stack([t.reshape(-1) for t in self.slots]))
                 self.barrier.wait()
+
+            def all_reduce(self, t):
+                self.slots[self.rank] = t
+                self.barrier.wait()
+                total = torch.stack(list(self.slots)).sum(0)     # the same reduction on every rank
+                self.barrier.wait()                              # everybody has read every slot
+                t.copy_(total)
         return _Rank()
 
 
@@ -92,6 +105,7 @@ def test_tp_engine_two_ranks_in_lockstep_equal_single_gpu_engine(world):
     grp = _LockstepGroup(world)
     engines = [DecodeEngine(model, use_graph=False, tp_group=grp.view(r)) for r in range(world)]
     assert engines[1].P == world and engines[1].rank == 1 and engines[1].hs == shape.hidden // world
+    assert all(e.tp3 for e in engines)
     outs, errs = [None] * world, []
 
     def run(r):
@@ -111,4 +125,46 @@ def test_tp_engine_two_ranks_in_lockstep_equal_single_gpu_engine(world):
     torch.cuda.synchronize()
     for r in range(world):
         assert outs[r] is not None and torch.isfinite(outs[r]).all()
-        assert torch.equal(outs[r], ref), f"rank {r} of {world}"
+        assert torch.equal(outs[r], outs[0]), f"rank {r} of {world} disagrees with rank 0"     # every rank holds the same sums
+        assert (outs[r] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), f"rank {r} of {world}"
+        assert engines[r].n_collectives == 2 * shape.n_layers
+    assert (outs[0].argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tp_engine_7b_layer_shapes_in_lockstep(world):
+    """The shard geometry of Llama-2-7B's layers (hidden 4096, inter 11008, 32 heads): 31 INT4 groups of o_proj and 85 of
+    down_proj do not divide over 2 / 8 ranks -- boundary groups and the outlier slice are shared as fuse.column_shard says."""
+    import threading
+    from qeft_amd.llama import DecodeEngine, LlamaShape, QuantLlama
+    shape = LlamaShape(4096, 11008, 1, 32, 32, 1024, 64, n_out=128, name="7b-1layer")
+    model = QuantLlama(shape, DEV, seed=4, fast_init=True)
+    tokens = torch.randint(0, shape.vocab, (6,), generator=torch.Generator().manual_seed(5))
+    ref = DecodeEngine(model, use_graph=False).teacher_forced_logits(tokens)
+    grp = _LockstepGroup(world)
+    engines = [DecodeEngine(model, use_graph=False, tp_group=grp.view(r)) for r in range(world)]
+    assert all(e.tp3 for e in engines)
+    # a rank streams ~1/world of the weights (+ the shared boundary groups and outlier slices)
+    full = DecodeEngine(model, use_graph=False).weight_bytes_per_token()
+    per_rank = [e.weight_bytes_per_token() for e in engines]
+    assert max(per_rank) < full / world * (1.12 if world == 2 else 1.40)
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(DEV)
+            outs[r] = engines[r].teacher_forced_logits(tokens)
+        except Exception as e:
+            errs.append(e)
+            grp.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(outs[r], outs[0])
+        assert (outs[r] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
