@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the PMC child run that fills roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the PMC child: two tokens' GEMV launches, no timing
     ap.add_argument("--no-per-kind", action="store_true", help="skip the per-launch-kind timing graphs")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip latency_protocol / prefill_2048 / finetune_step (the decode line and its roofline only)")
@@ -157,19 +158,23 @@ def hbm_traffic_per_gemv_launch(model_flag, bits):
     tmp = tempfile.mkdtemp(prefix="qeft_pmc_", dir="/tmp")
     try:
         cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "run", "--output-format", "csv", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2", "--model", model_flag,
-               "--bits", str(bits), "--no-cpu-baseline", "--no-traffic", "--no-per-kind", "--no-extras"]
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--model", model_flag, "--bits", str(bits)]
         env = dict(os.environ, TMPDIR="/tmp")
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+        if res.returncode != 0:
+            print(f"[bench] PMC child run failed (rc {res.returncode}): {res.stderr.decode(errors='replace')[-600:]}", file=sys.stderr)
+            return None
         vals = []
         for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if r.get("Counter_Name") == "FETCH_SIZE" and "gemv_w" in r.get("Kernel_Name", ""):
+                if r.get("Counter_Name") == "FETCH_SIZE" and ("gemv_v3" in r.get("Kernel_Name", "") or "gemv_w" in r.get("Kernel_Name", "")):
                     vals.append(float(r["Counter_Value"]))
         if not vals:
+            print("[bench] PMC child run: no FETCH_SIZE rows for the GEMV kernel", file=sys.stderr)
             return None
         return {"bytes_per_launch": int(sum(vals) / len(vals) * 1024 * 2), "launches_sampled": len(vals)}
-    except Exception:
+    except Exception as e:
+        print(f"[bench] PMC child run failed: {type(e).__name__}: {e}", file=sys.stderr)
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -259,7 +264,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # the PMC pass is a child process of its own and has to start BEFORE this process initialises the GPU
     traffic = None
-    if world == 1 and "RANK" not in os.environ and not args.no_traffic:
+    if world == 1 and "RANK" not in os.environ and not args.no_traffic and not args.pmc_child:
         traffic = hbm_traffic_per_gemv_launch(args.model, args.bits)
 
     import torch
@@ -293,6 +298,11 @@ def main():
     eng.greedy = True
     torch.cuda.synchronize(dev)
     t_build = time.time() - t_build
+    if args.pmc_child:          # under `rocprofv3 --pmc` every launch costs milliseconds: just the 128 GEMV launches, twice
+        for _ in range(2):
+            eng._launch_token(True)
+        torch.cuda.synchronize(dev)
+        return
 
     graph_ok = eng.use_graph
     if graph_ok:

@@ -23,12 +23,20 @@ def model7b():
 
 
 def _compare(got, ref, tokens, nll=True):
+    """nll=True: the SURVEY criterion |dNLL| <= 1e-3 on the run's mean.  The per-token difference is zero-mean noise of
+    standard deviation ~7e-3 (fp16 activations / logits; tools/nll_probe.py), so a mean over T tokens scatters by
+    7e-3 / sqrt(T): 7e-4 at T = 96, 3e-4 at T = 512 -- the strict bound is only meaningful on the long run.  Every run checks
+    that the mean is consistent with zero (within 3.5 standard errors: no systematic bias), the logits and the argmax."""
+    import torch.nn.functional as F
     from qeft_amd.llama import nll_from_logits
     scale = ref.abs().max().item()
     err = (got - ref).abs().max().item() / scale
     dn = abs(nll_from_logits(got, tokens) - nll_from_logits(ref, tokens))
-    print(f"[7b parity] T={tokens.numel()} max|dlogit|/max|logit|={err:.3e} |dNLL|={dn:.3e}")
+    d = F.cross_entropy(got[:-1].float(), tokens[1:], reduction="none") - F.cross_entropy(ref[:-1].float(), tokens[1:], reduction="none")
+    sem = d.std().item() / (d.numel() ** 0.5)
+    print(f"[7b parity] T={tokens.numel()} max|dlogit|/max|logit|={err:.3e} |dNLL|={dn:.3e} (per-token std {d.std().item():.2e}, s.e.m. {sem:.2e})")
     assert err < LOGIT_TOL, err
+    assert abs(d.mean().item()) <= 3.5 * sem + 1e-4, (d.mean().item(), sem)
     assert not nll or dn <= NLL_TOL, dn
     # the argmax sequence agrees wherever the dense model's top-2 margin exceeds the logit tolerance
     top2 = ref.topk(2, dim=-1).values
@@ -38,8 +46,8 @@ def _compare(got, ref, tokens, nll=True):
 
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_engine_7b_first_tokens(model7b, use_graph):
-    """96 tokens from position 0 (one attention block per head throughout): hipGraph replay and eager launches.  (The mean
-    NLL of a run is noise-limited at ~ logit error / sqrt(T): 24 tokens sit at 0.3-1.1e-3 from build to build, 96 at half that.)"""
+    """96 tokens from position 0 (one attention block per head throughout): hipGraph replay and eager launches -- logits,
+    argmax and an unbiased NLL (the strict |dNLL| <= 1e-3 is checked on the 512-token run below: see _compare)."""
     from qeft_amd.llama import DecodeEngine
     model, dense = model7b
     eng = DecodeEngine(model, use_graph=use_graph)
@@ -47,15 +55,16 @@ def test_engine_7b_first_tokens(model7b, use_graph):
     got = eng.teacher_forced_logits(tokens)
     ref = model.forward_dense_reference(tokens, dense)
     torch.cuda.synchronize()
-    _compare(got, ref, tokens)
+    _compare(got, ref, tokens, nll=False)
 
 
 def test_engine_7b_crosses_position_256(model7b):
-    """272 tokens: the engine switches from the 1-block-per-head graph to the 4-block one at position 256."""
+    """512 tokens (the whole KV cache of this fixture): |dNLL| <= 1e-3, and the engine switches from the 1-block-per-head
+    graph to the 4-block one at position 256."""
     from qeft_amd.llama import DecodeEngine
     model, dense = model7b
     eng = DecodeEngine(model, use_graph=True)
-    tokens = torch.randint(0, model.shape.vocab, (272,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    tokens = torch.randint(0, model.shape.vocab, (512,), generator=torch.Generator().manual_seed(2)).to(DEV)
     got = eng.teacher_forced_logits(tokens)
     assert {sp for sp, _ in eng.graphs} >= {1, 4}       # both splits were captured and replayed
     ref = model.forward_dense_reference(tokens, dense)
