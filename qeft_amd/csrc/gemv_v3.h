@@ -65,6 +65,7 @@ struct V3Args {
     float* y32;             // PLAIN with residual: [N]
     f16* ynorm;
     float* ssq_out;
+    long long* dbg;         // lab only (ABL & 8): per block 8 x 100 MHz time stamps of wave 0; never read in the product
 };
 
 // ---- LDS carve-up (bytes); every DMA-filled region is a whole number of 1 KB pieces
@@ -169,6 +170,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
     const int nl = lane & 15, kc = lane >> 4;
     int set0, RS;
     v3_block_sets(v3_xcd_block(blockIdx.x, nblk), sets_q, sets_r, set0, RS);
+    long long ts[7] = {0, 0, 0, 0, 0, 0, 0};    // ABL & 8: entry, ring issued, staging landed (barrier), steps done, (end), all waves done (barrier), values ready
+    if (ABL & 8) ts[0] = wall_clock64();
 
     // ---- 1. staging by LDS-DMA.  x: the waves take pieces w, w + NW, ..; per row set the scale words (piece j = wave) and
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (ABL & 8) ts[1] = wall_clock64();
     // ---- 3. staged data complete: this wave's pieces are older than its D ring loads
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
     // ---- 2b. epilogue-only operands, requested BEHIND the ring (they must not delay the weight stream): wave 1 the
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (ABL & 8) ts[2] = wall_clock64();
 
     // ---- 4. steps.  acc[rs]: lanes kc == 0 hold row nl of row set rs (batch row 0 = D row 0, register 0)
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
         }
         fold();                                // the last (step, row set)
     }
+    if (ABL & 8) ts[3] = wall_clock64();
     if (kc == 0) {
         red[(0 * NW + wave) * 16 + nl] = acc0;
         if (RS > 1) red[(1 * NW + wave) * 16 + nl] = acc1;
@@ -369,14 +375,19 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
     // ---- 5. combine the waves, finish the norm, fused epilogues
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // step 2b's pieces (a wave without ring steps never waited)
     __syncthreads();
+    if (ABL & 8) ts[5] = wall_clock64();
     float rs_norm = 1.f;
     if (ssq_in) {               // every wave sums the (<= 512) partials itself, in a fixed order: no second barrier
-        float s = (lane < ssq_n ? ssql[lane] : 0.f);
+        // all reads first, unconditionally (a guarded read is a branch with its own wait: 8 dependent LDS round trips cost
+        // 0.5 us of every q|k|v and gate|up launch); what lies past the array is dropped by a select, never added
+        float pv[V3_MAX_SSQ / 64];
 #pragma unroll
-        for (int i = 1; i < V3_MAX_SSQ / 64; ++i) s += (lane + 64 * i < ssq_n ? ssql[lane + 64 * i] : 0.f);
+        for (int i = 0; i < V3_MAX_SSQ / 64; ++i) pv[i] = ssql[lane + 64 * i];
+        float s = 0.f;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        rs_norm = rsqrtf(s / (float)G.K + eps);
+        for (int i = 0; i < V3_MAX_SSQ / 64; ++i) s += (lane + 64 * i < ssq_n) ? pv[i] : 0.f;
+        s = wave_sum(s);
+        rs_norm = __builtin_amdgcn_rsqf(s * (1.f / (float)G.K) + eps);
     }
     auto row_sum = [&](int rs, int n) {
         float v = 0.f;
@@ -395,7 +406,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
                 uv += (float)bias[(set0 + rs) * 16 + 8 + n];
             }
             const f16 g16 = (f16)gv, u16 = (f16)uv;
-            yout[(set0 + rs) * 8 + n] = (f16)(silu_f32((float)g16) * (float)u16);
+            const f16 r16 = (f16)(silu_f32((float)g16) * (float)u16);
+            if (ABL & 8) { asm volatile("" :: "v"(r16)); ts[6] = wall_clock64(); }
+            yout[(set0 + rs) * 8 + n] = r16;
+        }
+        if (ABL & 8) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) {
+                for (int i = 0; i < 4; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
+                a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5];
+                a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6];
+                a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+            }
         }
         return;
     }
@@ -404,6 +426,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
         const int row = set0 * 16 + tid;
         float v = row_sum(tid >> 4, tid & 15);
         if (bias) v += (float)bias[row];
+        if (ABL & 8) { asm volatile("" :: "v"(v)); ts[6] = wall_clock64(); }
         if (residual) {
             v += ((const float*)epl)[tid];                          // lanes [0, 16) x 4 floats = the block's RS * 16 rows
             y32[row] = v;
@@ -416,9 +439,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
         }
     }
     if (residual && gamma_out && wave == 0) {   // RS * 16 <= 64: the block's rows all sit in wave 0
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        sq = wave_sum(sq);
         if (lane == 0) ssq_out[blockIdx.x] = sq;
+    }
+    if (ABL & 8) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            for (int i = 0; i < 4; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
+            a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5];
+            a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6];
+            a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+        }
     }
 }
 #endif  // __HIPCC__

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 W4 kernels.  HIP / CDNA4 only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace qeft {
@@ -16,6 +17,23 @@ typedef u32x3 u32x3_u __attribute__((aligned(4)));   // 12-byte records of the 3
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Sum over the 64 lanes of a wave, the same value returned in every lane.  DPP adds inside the 16-lane rows (4 VALU
+// instructions with a few cycles of latency each) and four v_readlane across the rows: a __shfl_xor butterfly is six
+// DEPENDENT ds_bpermute round trips through the LDS crossbar, ~0.4 us at the end of every launch that carries one.
+__device__ __forceinline__ float wave_sum(float v) {
+    auto dpp_add = [](float x, auto ctrl_tag) {
+        constexpr int CTRL = decltype(ctrl_tag)::value;
+        const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
+        return x + __builtin_bit_cast(float, t);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});     // row_half_mirror: sums of 8
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});     // row_mirror: every lane holds its row's (16 lanes) sum
+    const int iv = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
+}
 __device__ __forceinline__ h2 as_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
 __device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ h2 splat(f16 v) { return h2{v, v}; }

@@ -88,6 +88,56 @@ static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h3
     printf("  %-4s NW=%2d D=%d blocks=%4d ABL=%d : %7.2f us  %6.0f GB/s\n", kd.name, NW, D, nblk, ABL, us, bytes / us / 1e3);
 }
 
+// ABL = 8: time stamps of wave 0 of every block (100 MHz ticks) -> where a launch's time goes
+template <int NW, int D>
+static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk) {
+    const int nsets = kd.n / 16;
+    V3Args a{};
+    a.x = (const f16*)x;
+    a.g = V3Geom{kd.k, 128, kd.k / 128, (kd.k - 128) / 128, kd.k / 128, nsets};
+    a.rs_cap = (nsets + nblk - 1) / nblk; a.nblk = nblk; a.sets_q = nsets / nblk; a.sets_r = nsets % nblk;
+    a.ssq_in = kd.ssq ? (const float*)ssq : nullptr; a.n_ssq_in = kd.ssq ? 256 : 0; a.eps = 1e-5f;
+    a.residual = kd.res ? (const float*)h32 : nullptr; a.y32 = kd.res ? (float*)h32 : nullptr;
+    a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
+    a.y = (f16*)y;
+    long long* dbg; CK(hipMalloc(&dbg, (size_t)nblk * 64 * 6));
+    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap);
+    std::vector<long long> h((size_t)nblk * 8 * 6);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int warm = 0; warm < 3; ++warm)
+        for (int l = 0; l < 6; ++l) {
+            V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
+            b.dbg = dbg + (size_t)l * nblk * 8;
+            if (l == 0 && warm == 2) CK(hipEventRecord(e0, 0));
+            if (kd.mode == V3_MODE_PAIR) launch<NW, D, V3_MODE_PAIR, 8>(b, nblk, smem); else launch<NW, D, V3_MODE_PLAIN, 8>(b, nblk, smem);
+        }
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    printf("  %-4s NW=%2d D=%d blocks=%4d: %.2f us per launch (6 back to back); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, ms * 1e3 / 6);
+    long long prev_end = 0;
+    for (int l = 0; l < 6; ++l) {
+        long long t0 = 1LL << 62, mx[7] = {0, 0, 0, 0, 0, 0, 0}, mn[7];
+        for (int i = 0; i < 7; ++i) mn[i] = 1LL << 62;
+        double tail[3] = {0, 0, 0};      // mean over blocks: wave 0's steps done -> barrier, barrier -> values ready, values ready -> stores acknowledged
+        for (int b = 0; b < nblk; ++b) {
+            const long long* p = &h[((size_t)l * nblk + b) * 8];
+            if (p[0] < t0) t0 = p[0];
+            for (int i = 0; i < 7; ++i) { if (p[i] < mn[i]) mn[i] = p[i]; if (p[i] > mx[i]) mx[i] = p[i]; }
+            tail[0] += (p[5] - p[3]) / 100.0 / nblk; tail[1] += (p[6] - p[5]) / 100.0 / nblk; tail[2] += (p[4] - p[6]) / 100.0 / nblk;
+        }
+        printf("     launch %d: entry 0..%.2f | ring issued %.2f..%.2f | staging landed %.2f..%.2f | steps done %.2f..%.2f | end %.2f..%.2f", l,
+               (mx[0] - t0) / 100.0, (mn[1] - t0) / 100.0, (mx[1] - t0) / 100.0, (mn[2] - t0) / 100.0, (mx[2] - t0) / 100.0,
+               (mn[3] - t0) / 100.0, (mx[3] - t0) / 100.0, (mn[4] - t0) / 100.0, (mx[4] - t0) / 100.0);
+        printf(" | tail per block: wait for the block's waves %.2f, epilogue math %.2f, store + ack %.2f", tail[0], tail[1], tail[2]);
+        if (l) printf(" | gap since previous end %.2f", (t0 - prev_end) / 100.0);
+        printf("\n");
+        prev_end = mx[4];
+    }
+    CK(hipFree(dbg));
+}
+
 int main() {
     const int L = 12;
     uint32_t* out; CK(hipMalloc(&out, 4096));
@@ -134,6 +184,9 @@ int main() {
         run<8, 4, 1>(kd, B, x, y, h32, gam, ssq, ynorm, nb);     // no bias-sum MFMAs
         run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);     // no math at all
         run<16, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        if (nb <= 256) timeline<16, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        timeline<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        timeline<8, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
         (void)hipFree(x); (void)hipFree(y);
     }
