@@ -241,8 +241,17 @@ def gemm_records(dev, m=2048, layers=4, reps=25):
         t_f = _event_time_us(fwd, reps, dev) / layers
         t_x = _event_time_us(dx, reps, dev) / layers
         t_w = _event_time_us(dow, reps, dev) / layers
+        # context, not a baseline: the library's dense fp16 GEMM of the same shape (hipBLASLt through torch; 4x the weight bytes)
+        wd = [torch.randn(n, k, device=dev).half() for _ in range(layers)]
+
+        def dense():
+            for w_ in wd:
+                torch.matmul(x, w_.t())
+        t_d = _event_time_us(dense, reps, dev) / layers
+        del wd
         fwd_recs.append({"shape": f"{n}x{k}", "us": round(t_f, 1), "TFLOPs": round(flops / t_f / 1e6, 1),
-                         "frac_of_peak": round(flops / t_f / 1e6 / MFMA_PEAK_TFLOPS, 4), "variant": variants["fwd"]})
+                         "frac_of_peak": round(flops / t_f / 1e6 / MFMA_PEAK_TFLOPS, 4), "variant": variants["fwd"],
+                         "hipblaslt_dense_fp16_us": round(t_d, 1), "hipblaslt_dense_fp16_TFLOPs": round(flops / t_d / 1e6, 1)})
         ft_recs.append({"shape": f"{n}x{k}", "forward_us": round(t_f, 1), "dx_us": round(t_x, 1), "dow_us": round(t_w, 1),
                         "step_us": round(t_f + t_x + t_w, 1),
                         "dx_TFLOPs": round(flops / t_x / 1e6, 1), "dx_frac_of_peak": round(flops / t_x / 1e6 / MFMA_PEAK_TFLOPS, 4),
@@ -423,7 +432,7 @@ def main():
                 lin_flops = 2.0 * 2048 * sum(n * k for n, k in ((4096, 4096),) * 4 + ((11008, 4096),) * 2 + ((4096, 11008),)) * shape.n_layers
                 pre["whole_model"] = {"ms": round(t_pre / 1e3, 2), "tokens_per_s": round(2048 / t_pre * 1e6, 0),
                                       "linears_TFLOP": round(lin_flops / 1e12, 2),
-                                      "note": "2048-token prompt through every packed linear (GEMM path), torch SDPA attention"}
+                                      "note": "2048-token prompt through every packed linear (GEMM path), torch fused SDPA attention"}
                 extras["prefill_2048"] = pre
                 extras["finetune_step"] = {"M": 2048, "per_shape": ft_recs,
                                            "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44)"}

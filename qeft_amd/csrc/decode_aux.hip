@@ -12,8 +12,7 @@
 namespace qeft {
 
 __device__ __forceinline__ float block_sum_256(float v, float* sm) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) sm[wave] = v;

@@ -378,14 +378,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
     if (ABL & 8) ts[5] = wall_clock64();
     float rs_norm = 1.f;
     if (ssq_in) {               // every wave sums the (<= 512) partials itself, in a fixed order: no second barrier
-        // all reads first, unconditionally (a guarded read is a branch with its own wait: 8 dependent LDS round trips cost
-        // 0.5 us of every q|k|v and gate|up launch); what lies past the array is dropped by a select, never added
-        float pv[V3_MAX_SSQ / 64];
-#pragma unroll
-        for (int i = 0; i < V3_MAX_SSQ / 64; ++i) pv[i] = ssql[lane + 64 * i];
+        // two unconditional 16-byte reads per lane (a guarded read is a branch with its own wait); what lies past the array
+        // is dropped by a select, never added.  The wave sum is DPP + readlane (qeft_common.h): with eight guarded reads and
+        // a shuffle butterfly this block cost 0.5 us of every q|k|v and gate|up launch
+        typedef float v3f4 __attribute__((ext_vector_type(4)));
+        const v3f4 p0 = ((const v3f4*)ssql)[lane], p1 = ((const v3f4*)ssql)[lane + 64];     // partials 4 lane .. + 3 and 256 + the same
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < V3_MAX_SSQ / 64; ++i) s += (lane + 64 * i < ssq_n) ? pv[i] : 0.f;
+        for (int j = 0; j < 4; ++j) s += (4 * lane + j < ssq_n ? p0[j] : 0.f) + (256 + 4 * lane + j < ssq_n ? p1[j] : 0.f);
         s = wave_sum(s);
         rs_norm = __builtin_amdgcn_rsqf(s * (1.f / (float)G.K) + eps);
     }

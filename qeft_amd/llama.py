@@ -236,8 +236,10 @@ def prefill(model: "QuantLlama", tokens, engine=None):
             engine.vc[li][:, :T] = v.transpose(0, 1)
         rep = s.n_heads // s.n_kv_heads
         kk, vv = (k, v) if rep == 1 else (k.repeat_interleave(rep, 1), v.repeat_interleave(rep, 1))
-        a = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1), kk.transpose(0, 1), vv.transpose(0, 1),
-                                                             is_causal=True)           # [H, T, 128]
+        # 4-D operands: torch routes an unbatched [H, T, 128] call to its math path (1.6 ms per layer at T = 2048 on this
+        # build) and a batched one to the fused kernel (0.14 ms) -- tools/sdpa_probe.py
+        a = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], kk.transpose(0, 1)[None],
+                                                             vv.transpose(0, 1)[None], is_causal=True)[0]    # [H, T, 128]
         a = a.transpose(0, 1).reshape(T, s.hidden).contiguous()
         h = h + at.o_proj(a)                                          # o_proj gathers its own column order
         x = _rmsnorm(h, L.post_attention_layernorm, s.rms_eps)
