@@ -1596,28 +1596,33 @@ __global__ __launch_bounds__(256) void grad_oweight_mfma_kernel(const f16* __res
         u32x4 d[2];    // dy: items tid, tid + 256 -> (row = item >> 2, 16-byte piece = item & 3)
         u32x4 xv[4];   // x_o: items tid + 256 i  -> (row = item >> 3, piece = item & 7)
     };
+    // loads are unconditional (clamped addresses): a load in a branch makes hipcc drain vmcnt(0) on the spot, which would
+    // empty the ring of stages below; what lies outside [M) x [N) / [R) is zeroed when the stage is written to LDS
     auto gload = [&](int m0, Stage& st) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int item = tid + 256 * i, m = m0 + (item >> 2), n = n0 + (item & 3) * 8;
-            st.d[i] = (m < M && n < N) ? *(const u32x4*)(dy + (size_t)m * N + n) : u32x4{0u, 0u, 0u, 0u};
+            const int item = tid + 256 * i, m = min(m0 + (item >> 2), M - 1), n = min(n0 + (item & 3) * 8, N - 8);
+            st.d[i] = *(const u32x4*)(dy + (size_t)m * N + n);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int item = tid + 256 * i, m = m0 + (item >> 3), j = j0 + (item & 7) * 8;
-            st.xv[i] = (m < M && j < R) ? *(const u32x4*)(x + (size_t)m * K + kq + j) : u32x4{0u, 0u, 0u, 0u};
+            const int item = tid + 256 * i, m = min(m0 + (item >> 3), M - 1), j = min(j0 + (item & 7) * 8, R - 8);
+            st.xv[i] = *(const u32x4*)(x + (size_t)m * K + kq + j);
         }
     };
-    auto lstore = [&](const Stage& st) {
+    auto lstore = [&](const Stage& st, int m0) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int item = tid + 256 * i;
-            *(u32x4*)(lds_dy + (item >> 2) * GO_PDY + (item & 3) * 16) = st.d[i];
+            const bool ok = m0 + (item >> 2) < M && n0 + (item & 3) * 8 < N;
+            *(u32x4*)(lds_dy + (item >> 2) * GO_PDY + (item & 3) * 16) = ok ? st.d[i] : z;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int item = tid + 256 * i;
-            *(u32x4*)(lds_x + (item >> 3) * GO_PX + (item & 7) * 16) = st.xv[i];
+            const bool ok = m0 + (item >> 3) < M && j0 + (item & 7) * 8 < R;
+            *(u32x4*)(lds_x + (item >> 3) * GO_PX + (item & 7) * 16) = ok ? st.xv[i] : z;
         }
     };
     // transposed-read addresses (16-m step 0): lane 4q+p of a 16-lane group addresses row q, columns 4p.. of its block;
@@ -1627,12 +1632,12 @@ __global__ __launch_bounds__(256) void grad_oweight_mfma_kernel(const f16* __res
     const uint32_t a_tr = (uint32_t)(uintptr_t)lds_dy + rowsel * GO_PDY + colsel;
     const uint32_t b_tr = (uint32_t)(uintptr_t)lds_x + rowsel * GO_PX + colsel;
 
-    Stage cur, nxt;
-    gload(0, cur);
-    for (int m0 = 0; m0 < M; m0 += GO_BM) {
-        lstore(cur);
+    // Three stages in flight (registers): with one, a block spent ~0.9 us per 128-row stage waiting for its own loads
+    // (15 us for M = 2048; the launch is 3 % of the step's flops).  Rows past M load as zeros, so the ring needs no tail logic.
+    auto body = [&](Stage& st, int m0, int m_refill) {
+        lstore(st, m0);
         __syncthreads();
-        if (m0 + GO_BM < M) gload(m0 + GO_BM, nxt);
+        gload(m_refill, st);
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const uint32_t row = (uint32_t)(wave * 2 + ss) * 16;
@@ -1651,7 +1656,15 @@ __global__ __launch_bounds__(256) void grad_oweight_mfma_kernel(const f16* __res
                     af, __builtin_bit_cast(h8, u32x4{b[jt][0][0], b[jt][0][1], b[jt][1][0], b[jt][1][1]}), acc[jt], 0, 0, 0);
         }
         __syncthreads();
-        cur = nxt;
+    };
+    Stage s0, s1, s2;
+    gload(0, s0);
+    gload(GO_BM, s1);
+    gload(2 * GO_BM, s2);
+    for (int m0 = 0; m0 < M; m0 += 3 * GO_BM) {
+        body(s0, m0, m0 + 3 * GO_BM);
+        body(s1, m0 + GO_BM, m0 + 4 * GO_BM);          // past M: a stage of zeros
+        body(s2, m0 + 2 * GO_BM, m0 + 5 * GO_BM);
     }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
