@@ -41,8 +41,9 @@ def build(force=False, verbose=True, extra_flags=()):
     procs = []
     for s in SOURCES:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        lab = ["-DQEFT_LAB"] if os.environ.get("QEFT_BUILD_LAB") == "1" else []      # tools/gemm_clock_lab.py, QEFT_GEMM_ABL
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", obj,
-               *extra_flags]
+               *lab, *extra_flags]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

@@ -789,6 +789,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                 return hipGetLastError();
             };
             g_last_variant = "gemm_v3_256x128";
+#ifdef QEFT_LAB      // lab builds only (QEFT_BUILD_LAB=1 python -m qeft_amd.build): ablations / time stamps, wrong results by design
             static const int abl = getenv("QEFT_GEMM_ABL") ? atoi(getenv("QEFT_GEMM_ABL")) : 0;
             if (abl == 1) return go3(gemm_w4_kernel_v3<true, 1>);
             if (abl == 2) return go3(gemm_w4_kernel_v3<true, 2>);
@@ -796,6 +797,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             if (abl == 4) return go3(gemm_w4_kernel_v3<true, 4>);
             if (abl == 5) return go3(gemm_w4_kernel_v3<true, 5>);
             if (abl == 6) return go3(gemm_w4_kernel_v3<true, 6>);
+#endif
             return outl ? go3(gemm_w4_kernel_v3<true>) : go3(gemm_w4_kernel_v3<false>);
         }
     }

@@ -1,4 +1,5 @@
-"""Lab: shader clock during the v3 GEMM's k loop (QEFT_GEMM_ABL=6 builds timestamps into the kernel; the 'bias' buffer
+"""Lab (needs a lab build of the library: QEFT_BUILD_LAB=1 python -m qeft_amd.build --force):
+shader clock during the v3 GEMM's k loop (QEFT_GEMM_ABL=6 selects the kernel variant with time stamps; the 'bias' buffer
 receives, per block, [shader cycles, 100 MHz ticks, start tick, end tick] of compute wave 0's k loop)."""
 import os
 import sys
