@@ -42,8 +42,9 @@ def build(force=False, verbose=True, extra_flags=()):
     for s in SOURCES:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         lab = ["-DQEFT_LAB"] if os.environ.get("QEFT_BUILD_LAB") == "1" else []      # tools/gemm_clock_lab.py, QEFT_GEMM_ABL
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", obj,
-               *lab, *extra_flags]
+        # kernarg preload: the leading kernel parameters arrive in SGPRs at wave launch (gemv_v3.h orders its parameters for it)
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+               "-c", os.path.join(CSRC, s), "-o", obj, *lab, *extra_flags]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

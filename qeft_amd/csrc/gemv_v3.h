@@ -68,6 +68,31 @@ struct V3Args {
     long long* dbg;         // lab only (ABL & 8): per block 8 x 100 MHz time stamps of wave 0; never read in the product
 };
 
+// What the kernel receives.  The first 16 dwords of the kernel-argument segment -- the four operand pointers and the
+// geometry the prologue needs before it can issue its DMA pieces and ring loads -- are plain leading parameters so that
+// they can be PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16: no scalar-memory round trip
+// between a wave's first instruction and its first load); everything only the later phases read travels in V3Tail.
+struct V3Tail {
+    const float* ssq_in;
+    const float* residual;
+    const f16* gamma_out;
+    const f16* bias;
+    f16* y;
+    float* y32;
+    f16* ynorm;
+    float* ssq_out;
+    long long* dbg;
+    int n_out, nsteps, nsets, n_ssq_in;
+    float eps;
+};
+inline V3Tail v3_tail(const V3Args& a) {
+    return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps};
+}
+// 13 dwords (14 user SGPRs are available for preloading next to the kernarg pointer): grid size | rs_cap << 24 and
+// sets_q | sets_r << 16 share a dword each (nblk, sets_r < 65536: gemv_v3_launch checks)
+#define V3_KERNEL_ARGS(a) (a).qw, (a).x, (a).szp, (a).ow, (a).g.K, (a).g.nfull, (a).g.ngroups, \
+    (uint32_t)(a).nblk | ((uint32_t)(a).rs_cap << 24), (uint32_t)(a).sets_q | ((uint32_t)(a).sets_r << 16), qeft::v3_tail(a)
+
 // ---- LDS carve-up (bytes); every DMA-filled region is a whole number of 1 KB pieces
 __host__ __device__ constexpr int v3_x_bytes(int K) { return (K * 2 + 1023) / 1024 * 1024; }
 __host__ __device__ constexpr int v3_sz_bytes(int ngroups) { return (ngroups * 64 + 1023) / 1024 * 1024; }   // per row set
@@ -132,28 +157,29 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
 // NW waves per block (8, or 16 for launches of one block per CU: twice the instruction streams per SIMD for the same bytes);
 // wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
 template <int NW, int D, bool OUTL, int MODE, int ABL = 0>
-__global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
+__global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
+                                                          int K_, int nfull_, int ngroups_, uint32_t nblk_rscap, uint32_t setsq_setsr,
+                                                          V3Tail a) {
     static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
-    // every argument the prologue needs is copied to registers here, in one batch of scalar loads behind ONE wait: argument
-    // loads that hipcc leaves next to their first use each cost a dependent scalar-memory round trip
-    V3Geom G = a.g;
-    const int rs_cap = a.rs_cap, nblk = a.nblk, sets_q = a.sets_q, sets_r = a.sets_r, ssq_n = a.n_ssq_in;
+    // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
+    // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
+    // dependent scalar-memory round trip in the middle of the stream
+    V3Geom G{K_, a.n_out, a.nsteps, nfull_, ngroups_, a.nsets};
+    const int nblk = (int)(nblk_rscap & 0xffffffu), rs_cap = (int)(nblk_rscap >> 24);
+    const int sets_q = (int)(setsq_setsr & 0xffffu), sets_r = (int)(setsq_setsr >> 16);
+    const int ssq_n = a.n_ssq_in;
     const float eps = a.eps;
     const f16* const bias = a.bias;
     f16* const yout = a.y;
     float* const y32 = a.y32;
     f16* const ynorm = a.ynorm;
     float* const ssq_out = a.ssq_out;
-    const uint8_t* const xptr = (const uint8_t*)a.x;
-    const uint8_t* const qw = a.qw;
-    const uint8_t* const szp = a.szp;
-    const uint8_t* const ow = a.ow;
+    const uint8_t* const xptr = (const uint8_t*)x_in;
     const uint8_t* const ssq_in = (const uint8_t*)a.ssq_in;
     const uint8_t* const residual = (const uint8_t*)a.residual;
     const uint8_t* const gamma_out = (const uint8_t*)a.gamma_out;
-    asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(G.nsteps), "s"(rs_cap), "s"(nblk), "s"(sets_q), "s"(sets_r),
-                 "s"(ssq_n), "s"(xptr), "s"(qw), "s"(szp), "s"(ow), "s"(ssq_in), "s"(residual), "s"(gamma_out));
-    asm volatile("" ::"s"(eps), "s"(bias), "s"(yout), "s"(y32), "s"(ynorm), "s"(ssq_out));
+    asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(rs_cap), "s"(nblk), "s"(sets_q), "s"(sets_r), "s"(xptr), "s"(qw),
+                 "s"(szp), "s"(ow));
 
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
     const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups);
@@ -214,6 +240,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(V3Args a) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    asm volatile("" ::"s"(G.nsteps), "s"(ssq_n), "s"(ssq_in), "s"(residual), "s"(gamma_out), "s"(eps), "s"(bias), "s"(yout), "s"(y32),
+                 "s"(ynorm), "s"(ssq_out));
     if (ABL & 8) ts[1] = wall_clock64();
     // ---- 3. staged data complete: this wave's pieces are older than its D ring loads
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");

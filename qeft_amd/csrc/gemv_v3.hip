@@ -38,7 +38,7 @@ static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hi
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, a);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
     return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN>);
@@ -65,7 +65,7 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     a.sets_q = a.g.nsets / nblk;
     a.sets_r = a.g.nsets % nblk;
     const size_t smem = v3_smem_bytes(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap);
-    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    if (smem > 160 * 1024 || nblk >= 65536) return hipErrorInvalidValue;       // (nblk, sets_r share dwords with rs_cap, sets_q)
     // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
     static const int f_nw = env_int("QEFT_GEMV_NW"), f_d = env_int("QEFT_GEMV_DEPTH");     // lab overrides
     // measured (tools/gemv_v3_lab.hip, profiles/r02_gemv_v3_lab.txt): 16 waves + depth 2 win where a CU holds one block and a

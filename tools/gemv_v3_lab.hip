@@ -1,6 +1,6 @@
 // Lab harness for the v3 decode GEMV (GPU box only): times kernel variants directly, cycling 12 weight sets per kind so that
 // nothing is served from L2 / MALL, on the four launch kinds of a Llama-2-7B decoder layer.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o gpurun_out/gemv_v3_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o /tmp/gemv_v3_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -61,7 +61,7 @@ template <int NW, int D, int MODE, int ABL>
 static void launch(const V3Args& a, int nblk, size_t smem) {
     auto kern = gemv_v3_kernel<NW, D, true, MODE, ABL>;
     if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, a);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, V3_KERNEL_ARGS(a));
 }
 
 template <int NW, int D, int ABL>
