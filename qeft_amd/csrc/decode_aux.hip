@@ -128,16 +128,20 @@ __device__ __forceinline__ size_t kcache_off(int p, int chunk, int max_seq) {
     return KFT ? ((size_t)chunk * max_seq + p) * 8 : (size_t)p * 128 + chunk * 8;
 }
 
-template <int PRE, int DH = 1, bool KFT = false>
-__global__ __launch_bounds__(256) void rope_attn_decode_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+// Parameter order: what the first loads need comes first -- the leading 13 dwords of the kernel-argument segment are
+// preloaded into SGPRs at wave launch (build flag -amdgpu-kernarg-preload-count), the rest arrives by scalar loads that
+// overlap those first vector loads.  DBG (lab only, tools/attn_timeline.py): per-wave phase stamps.
+template <int PRE, int DH = 1, bool KFT = false, bool DBG = false>
+__global__ __launch_bounds__(256) void rope_attn_decode_kernel(const int* __restrict__ pos_ptr, const int* __restrict__ out_pos,
+                                                               const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ v, const float* __restrict__ cs,
-                                                               const float* __restrict__ sn, f16* __restrict__ kc,
-                                                               f16* __restrict__ vc, const int* __restrict__ pos_ptr,
-                                                               const int* __restrict__ out_pos, f16* __restrict__ out,
-                                                               float* __restrict__ ws, int n_heads, int n_kv,
-                                                               int max_seq, int S, int tab_rows,
-                                                               unsigned long long* dbg) {
+                                                               uint32_t heads_kv_s_tab, const float* __restrict__ sn,
+                                                               f16* __restrict__ kc, f16* __restrict__ vc, f16* __restrict__ out,
+                                                               float* __restrict__ ws, int max_seq, unsigned long long* dbg_ptr) {
     constexpr int HD = 128;
+    const int n_heads = (int)(heads_kv_s_tab & 0xfffu), n_kv = (int)((heads_kv_s_tab >> 12) & 0xfffu);
+    const int S = (int)((heads_kv_s_tab >> 24) & 0xfu), tab_rows = (int)(heads_kv_s_tab >> 28);     // 1: cs / sn are this position's row; 0: the whole table
+    unsigned long long* const dbg = DBG ? dbg_ptr : nullptr;
     unsigned long long stamp[10];
     auto mark = [&](int i) {
         if (dbg) { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
@@ -586,9 +590,11 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(n_heads * S * dh), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v,
-                           (const float*)cs, (const float*)sn, (f16*)kc, (f16*)vc, pos, out_pos, (f16*)out, (float*)ws,
-                           n_heads, n_kv, max_seq, S, tab_rows, g_attn_dbg);
+        if (n_heads > 4095 || n_kv > 4095 || S > 15) return hipErrorInvalidValue;
+        const uint32_t packed = (uint32_t)n_heads | ((uint32_t)n_kv << 12) | ((uint32_t)S << 24) | ((tab_rows == 1 ? 1u : 0u) << 28);
+        hipLaunchKernelGGL(kern, dim3(n_heads * S * dh), dim3(256), smem, st, pos, out_pos, (const f16*)q, (const f16*)k,
+                           (const f16*)v, (const float*)cs, packed, (const float*)sn, (f16*)kc, (f16*)vc, (f16*)out, (float*)ws,
+                           max_seq, g_attn_dbg);
         return hipGetLastError();
     };
     // measured on the 7B decode step (contexts 64..192): 682 / 689 / 688 tokens/s with 1 / 2 / 4 blocks per head
@@ -596,6 +602,15 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
     if (k_ft_layout) {     // the reference's single_query_attention boundary: one block per head
         if (S != 1) return hipErrorInvalidValue;
         return launch(rope_attn_decode_kernel<4, 1, true>);
+    }
+    if (g_attn_dbg) {      // lab: the stamped variants
+        if (S == 1 && dh_env == 2) {
+            dh = 2;
+            return launch(rope_attn_decode_kernel<4, 2, false, true>);
+        }
+        if (S == 1) return launch(rope_attn_decode_kernel<4, 1, false, true>);
+        if (S == 2) return launch(rope_attn_decode_kernel<2, 1, false, true>);
+        return launch(rope_attn_decode_kernel<1, 1, false, true>);
     }
     if (S == 1 && dh_env == 2) {
         dh = 2;
