@@ -18,6 +18,8 @@ int token_begin_norm_blocks(int hidden);
 hipError_t residual_norm_launch(const void* h, const void* add, const void* gamma, void* h_out, void* hnorm, float* ssq_out,
                                 int hidden, hipStream_t st);
 hipError_t rmsnorm_f32_launch(const void* x, const void* gamma, void* y, int m, int H, float eps, hipStream_t st);
+hipError_t lm_head_f16_launch(const void* h32, const void* gamma, const void* W, void* logits, int H, int vocab, float eps,
+                              hipStream_t st);
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
 hipError_t gemv_w4_group_dispatch(GemvGroupArgs g, int nparts, hipStream_t st);
 hipError_t gemv_w4_silu_dispatch(const GemvArgs& a, hipStream_t st);
@@ -416,6 +418,16 @@ int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hid
     if (!x32 || !gamma || !y) return QEFT_ERR_NULL;
     if (!aligned16(x32) || !aligned16(y) || !aligned16(gamma)) return QEFT_ERR_ALIGN;
     return finish(qeft::rmsnorm_f32_launch(x32, gamma, y, m, hidden, eps, (hipStream_t)stream));
+}
+
+int qeft_lm_head_f16(const void* h32, const void* gamma, const void* weight, void* logits, int hidden, int vocab, float eps,
+                     qeft_stream_t stream) {
+    if (vocab < 1 || hidden < 512 || hidden % 512 != 0) return QEFT_ERR_SHAPE;
+    if (!h32 || !gamma || !weight || !logits) return QEFT_ERR_NULL;
+    if (!aligned16(h32) || !aligned16(gamma) || !aligned16(weight)) return QEFT_ERR_ALIGN;
+    hipError_t e = qeft::lm_head_f16_launch(h32, gamma, weight, logits, hidden, vocab, eps, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return QEFT_ERR_SHAPE;
+    return finish(e);
 }
 
 int qeft_silu_mul(const void* gate, const void* up, void* out, int n, qeft_stream_t stream) {

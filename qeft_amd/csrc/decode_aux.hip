@@ -491,6 +491,85 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restric
     for (int i = threadIdx.x; i < H; i += 256) y[base + i] = (f16)(x[base + i] * rs * (float)gamma[i]);
 }
 
+// Token tail of the decode harness: logits = fp16(W . fp16(rmsnorm(h32) * gamma)) for the fp16 head W [vocab][H] -- the final
+// RMSNorm and the head GEMV in one launch (hipBLASLt's GEMV of the 262 MB Llama-2 head ran at 4.7 TB/s behind a 9 us norm
+// launch).  Every block normalises the (16 KB, L2-resident) vector itself and keeps its lanes' slice of it in registers: a
+// wave then streams whole rows, 16 B per lane per load, 8 loads in flight per row and the next row's loads issued before
+// the current row is reduced; v_dot2_f32_f16 with fp32 accumulation, one DPP wave sum per row.  H = 512 * LPR.
+template <int LPR>
+__global__ __launch_bounds__(512) void lm_head_f16_kernel(const float* __restrict__ h32, const f16* __restrict__ gamma,
+                                                          const f16* __restrict__ W, f16* __restrict__ logits, int vocab,
+                                                          float eps, int rows_per_block) {
+    constexpr int H = 512 * LPR;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the lane's x elements: chunk c covers k = 512 c + 8 lane .. + 7
+    float xv[LPR][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < LPR; ++c) {
+        const f32x4 a = *(const f32x4*)(h32 + c * 512 + lane * 8), b = *(const f32x4*)(h32 + c * 512 + lane * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[c][j] = a[j];
+            xv[c][4 + j] = b[j];
+            ss += a[j] * a[j] + b[j] * b[j];
+        }
+    }
+    ss = wave_sum(ss);                          // every wave holds the whole vector: no block reduction
+    const float rs = rsqrtf(ss / (float)H + eps);
+    h2 xh[LPR][4];
+#pragma unroll
+    for (int c = 0; c < LPR; ++c) {
+        const h8 g = *(const h8*)(gamma + c * 512 + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)             // the rounding of qeft_rmsnorm_f32: fp16(x * rs * gamma)
+            xh[c][j] = h2{(f16)(xv[c][2 * j] * rs * (float)g[2 * j]), (f16)(xv[c][2 * j + 1] * rs * (float)g[2 * j + 1])};
+    }
+    (void)red;
+    const int r_end = min(vocab, (int)(blockIdx.x + 1) * rows_per_block);
+    int r = blockIdx.x * rows_per_block + wave;
+    u32x4 cur[LPR], nxt[LPR];
+    auto load_row = [&](int row, u32x4 (&dst)[LPR]) {
+        const u32x4* p = (const u32x4*)(W + (size_t)min(row, vocab - 1) * H) + lane;      // clamped: never out of range
+#pragma unroll
+        for (int c = 0; c < LPR; ++c) dst[c] = __builtin_nontemporal_load(p + c * 64);
+    };
+    load_row(r, cur);
+    for (; r < r_end; r += 8) {
+        load_row(r + 8, nxt);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < LPR; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_fdot2(as_h2(cur[c][j]), xh[c][j], acc, false);
+        acc = wave_sum(acc);
+        if (lane == 0) logits[r] = (f16)acc;
+#pragma unroll
+        for (int c = 0; c < LPR; ++c) cur[c] = nxt[c];
+    }
+}
+
+hipError_t lm_head_f16_launch(const void* h32, const void* gamma, const void* W, void* logits, int H, int vocab, float eps,
+                              hipStream_t st) {
+    const int blocks = vocab >= 4096 ? 512 : (vocab + 7) / 8, rpb = (vocab + blocks - 1) / blocks;
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), 0, st, (const float*)h32, (const f16*)gamma, (const f16*)W, (f16*)logits,
+                           vocab, eps, rpb);
+        return hipGetLastError();
+    };
+    switch (H) {
+        case 512: return go(lm_head_f16_kernel<1>);
+        case 1024: return go(lm_head_f16_kernel<2>);
+        case 2048: return go(lm_head_f16_kernel<4>);
+        case 4096: return go(lm_head_f16_kernel<8>);
+        case 5120: return go(lm_head_f16_kernel<10>);
+        case 8192: return go(lm_head_f16_kernel<16>);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 // end: tok = argmax(logits) when greedy (lowest index among equal maxima, like torch.argmax), pos += 1.  One block.
 __global__ __launch_bounds__(1024) void token_end_kernel(const f16* __restrict__ logits, long long* __restrict__ tok,
                                                          int* __restrict__ pos, int vocab, int greedy) {

@@ -597,6 +597,20 @@ class DecodeEngine:
         ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
                               1 if self.greedy else 0, st))
 
+    def _token_tail(self, h32, st):
+        """final RMSNorm + fp16 lm_head (one launch where the head's width is one the fused kernel takes) + token end"""
+        s, lib, ck = self.m.shape, self.lib, _lib.check
+        w = self.m.lm_head.weight
+        if s.hidden in (512, 1024, 2048, 4096, 5120, 8192) and w.dtype == torch.float16 and w.is_contiguous() \
+                and os.environ.get("QEFT_LM_HEAD_TORCH") != "1":
+            ck(lib.qeft_lm_head_f16(h32, self.m.model.norm.data_ptr(), w.data_ptr(), self.logits.data_ptr(), s.hidden, s.vocab,
+                                    s.rms_eps, st))
+        else:
+            ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, s.rms_eps, st))
+            torch.matmul(self.hn, w.t(), out=self.logits)
+        ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
+                              1 if self.greedy else 0, st))
+
     @torch.no_grad()
     def _launch_token_v3(self, linears_only=False, only=None):
         """One token on the v3 GEMV (gemv_v3.h): every quantized linear reads its fp16 input vector as it is; the RMSNorms
@@ -639,10 +653,7 @@ class DecodeEngine:
             ck(pick("d")(pk["d"], self.act.data_ptr(), h32, residual=h32, gamma_out=nxt))
         if linears_only:
             return
-        ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, eps, st))
-        torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
-        ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
-                              1 if self.greedy else 0, st))
+        self._token_tail(h32, st)
 
     @torch.no_grad()
     def _launch_token_tp3(self, linears_only=False, only=None):
@@ -691,10 +702,7 @@ class DecodeEngine:
                 ck(lib.qeft_residual_norm(part, None, nxt, h32, xn if nxt else None, ssq if nxt else None, s.hidden, st))
         if linears_only:
             return
-        ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, eps, st))
-        torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
-        ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
-                              1 if self.greedy else 0, st))
+        self._token_tail(h32, st)
 
     def capture(self, linears_only=False, only=None, split=None):
         """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires).  `split`:

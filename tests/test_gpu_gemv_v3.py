@@ -159,3 +159,24 @@ def test_token_begin_norm_and_final_norm():
     torch.cuda.synchronize()
     want = h * torch.rsqrt((h ** 2).mean() + 1e-5) * gamma.float()
     assert (y[0].float() - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("hidden,vocab", [(4096, 32000), (512, 1000), (5120, 777), (1024, 8)])
+def test_fused_final_norm_lm_head(hidden, vocab):
+    """qeft_lm_head_f16 == rmsnorm_f32 followed by the fp16 matmul (fp32 accumulation), row counts that do not divide
+    over the blocks / waves included."""
+    from qeft_amd import _lib
+    lib = _lib.lib()
+    torch.manual_seed(hidden + vocab)
+    h = torch.randn(hidden, device=DEV, dtype=torch.float32) * 3
+    gamma = (1 + 0.1 * torch.randn(hidden, device=DEV)).half()
+    w = (torch.randn(vocab, hidden, device=DEV) * 0.02).half()
+    logits = torch.full((vocab,), float("nan"), dtype=torch.float16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.qeft_lm_head_f16(h.data_ptr(), gamma.data_ptr(), w.data_ptr(), logits.data_ptr(), hidden, vocab, 1e-5, st))
+    hn = torch.empty(1, hidden, dtype=torch.float16, device=DEV)
+    _lib.check(lib.qeft_rmsnorm_f32(h.data_ptr(), gamma.data_ptr(), hn.data_ptr(), 1, hidden, 1e-5, st))
+    torch.cuda.synchronize()
+    want = hn[0].double() @ w.double().t()
+    assert torch.isfinite(logits).all()
+    assert (logits.double() - want).abs().max().item() <= 2e-3 * want.abs().max().item()
