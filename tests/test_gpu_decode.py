@@ -452,3 +452,29 @@ def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot):
     o2 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), None, None, T, rot, 10000.0, True)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
+
+
+def test_multi_token_graphs_equal_single_token_steps():
+    """DecodeEngine.run(n): graphs of 8 greedy tokens (token and position handed over on the device) give the same tokens,
+    logits and cache as n calls of step(); a run that is not a multiple of 8 and one that starts mid-way included."""
+    from qeft_amd.llama import DecodeEngine, QuantLlama, tiny_shape
+    shape = tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=512, max_seq=64)
+    model = QuantLlama(shape, DEV, seed=5)
+    a, b = DecodeEngine(model, use_graph=True), DecodeEngine(model, use_graph=True)
+    for e in (a, b):
+        e.greedy = True
+        e.reset()
+        e.tok.fill_(7)
+    toks = []
+    for _ in range(3 + 21):
+        a.step()
+        toks.append(int(a.tok.item()))
+    for _ in range(3):
+        b.step()
+    b.run(21)                       # 8 + 8 + 5 single steps
+    torch.cuda.synchronize()
+    assert any(len(k) == 3 for k in b.graphs)                     # a multi-token graph was captured and used
+    assert int(b.tok.item()) == toks[-1] and b.host_pos == a.host_pos == 24
+    assert torch.equal(a.logits, b.logits) and torch.equal(a.pos, b.pos)
+    for li in range(shape.n_layers):
+        assert torch.equal(a.kc[li][:, :24], b.kc[li][:, :24]) and torch.equal(a.vc[li][:, :24], b.vc[li][:, :24])
