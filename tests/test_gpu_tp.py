@@ -131,13 +131,14 @@ def test_tp_engine_two_ranks_in_lockstep_equal_single_gpu_engine(world):
     assert (outs[0].argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_tp_engine_7b_layer_shapes_in_lockstep(world):
-    """The shard geometry of Llama-2-7B's layers (hidden 4096, inter 11008, 32 heads): 31 INT4 groups of o_proj and 85 of
-    down_proj do not divide over 2 / 8 ranks -- boundary groups and the outlier slice are shared as fuse.column_shard says."""
+@pytest.mark.parametrize("world,dims", [(2, (4096, 11008, 32)), (8, (4096, 11008, 32)), (4, (5120, 13824, 40)), (8, (5120, 13824, 40))])
+def test_tp_engine_7b_13b_layer_shapes_in_lockstep(world, dims):
+    """The shard geometry of Llama-2-7B's and -13B's layers (BASELINE config 4): 31 / 39 INT4 groups of o_proj and 85 / 107 of
+    down_proj do not divide over the ranks -- boundary groups and the outlier slice are shared as fuse.column_shard says."""
     import threading
     from qeft_amd.llama import DecodeEngine, LlamaShape, QuantLlama
-    shape = LlamaShape(4096, 11008, 1, 32, 32, 1024, 64, n_out=128, name="7b-1layer")
+    hidden, inter, heads = dims
+    shape = LlamaShape(hidden, inter, 1, heads, heads, 1024, 64, n_out=128, name="1layer")
     model = QuantLlama(shape, DEV, seed=4, fast_init=True)
     tokens = torch.randint(0, shape.vocab, (6,), generator=torch.Generator().manual_seed(5))
     ref = DecodeEngine(model, use_graph=False).teacher_forced_logits(tokens)
@@ -147,7 +148,7 @@ def test_tp_engine_7b_layer_shapes_in_lockstep(world):
     # a rank streams ~1/world of the weights (+ the shared boundary groups and outlier slices)
     full = DecodeEngine(model, use_graph=False).weight_bytes_per_token()
     per_rank = [e.weight_bytes_per_token() for e in engines]
-    assert max(per_rank) < full / world * (1.12 if world == 2 else 1.40)
+    assert max(per_rank) < full / world * (1.12 if world == 2 else 1.40)      # measured: 1.03x at 2 ranks, 1.13x at 8
     outs, errs = [None] * world, []
 
     def run(r):
