@@ -10,7 +10,7 @@ namespace qeft {
 hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st);
 int gemv_v3_blocks(int nsets);
 bool gemv_v3_ok(int K, int G, int n_out);
-long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in);
+long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn);
 hipError_t token_begin_norm_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
                                    void* rope_row, const void* gamma, void* hnorm, float* ssq_out, int hidden, int vocab,
                                    int max_seq, hipStream_t st);
@@ -519,11 +519,30 @@ int qeft_decode_linear(const void* x, const void* qweight, const void* sz_packed
     return finish(qeft::gemv_v3_launch(a, mode, (hipStream_t)stream));
 }
 
+int qeft_decode_linear_hnorm(const void* h32, const void* gamma_x, const void* qweight, const void* sz_packed, const void* oweight,
+                             const void* bias, void* y, int n, int k, int group_size, int n_out, int mode, float eps,
+                             qeft_stream_t stream) {
+    if (!h32 || !gamma_x || !qweight || !sz_packed || !y || (n_out > 0 && !oweight)) return QEFT_ERR_NULL;
+    if (!aligned16(h32) || !aligned16(gamma_x) || !aligned16(qweight) || !aligned16(sz_packed) || (n_out > 0 && !aligned16(oweight)))
+        return QEFT_ERR_ALIGN;
+    qeft::V3Args a{};
+    if (int e = v3_geom(a.g, n, k, group_size, n_out, mode)) return e;
+    a.x = (const qeft::f16*)h32;              // fp32 [k]: the kernel reads it as such when xn_gamma is set
+    a.xn_gamma = (const qeft::f16*)gamma_x;
+    a.qw = (const uint8_t*)qweight;
+    a.szp = (const uint8_t*)sz_packed;
+    a.ow = (const uint8_t*)oweight;
+    a.bias = (const qeft::f16*)bias;
+    a.y = (qeft::f16*)y;
+    a.eps = eps;
+    return finish(qeft::gemv_v3_launch(a, mode, (hipStream_t)stream));
+}
+
 long long qeft_gemv_v3_check_extents(int n, int k, int group_size, int n_out, int n_ssq_in, int shrink_rows) {
     qeft::V3Geom G{};
     if (v3_geom(G, n, k, group_size, n_out, qeft::V3_MODE_PLAIN) != QEFT_OK) return -1;
     if (n_ssq_in < 0 || n_ssq_in > qeft::V3_MAX_SSQ) return -1;
-    return qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in);
+    return qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in, n_ssq_in == 0);
 }
 
 int qeft_token_begin_norm_blocks(int hidden) { return hidden >= 8 ? qeft::token_begin_norm_blocks(hidden) : 0; }

@@ -48,7 +48,9 @@ struct V3Geom {
 };
 
 struct V3Args {
-    const f16* x;           // [K] fp16, consumed as it is
+    const f16* x;           // [K] fp16, consumed as it is (xn_gamma == NULL), or the fp32 vector h [K] (xn_gamma != NULL)
+    const f16* xn_gamma;    // optional: x is fp32 h and the launch itself stages fp16(h * xn_gamma) and applies rsqrt(mean h^2 + eps)
+                            // to its row sums -- the whole RMSNorm on the consumer (tensor-parallel path: h comes out of an all-reduce)
     const uint8_t* qw;      // int16 [N/4][K] checkpoint layout
     const uint8_t* szp;     // u32 [N/16][ngroups][16] (scale | scaled_zero << 16), qeft_pack_scales
     const uint8_t* ow;      // fp16 [N][128] plain outlier rows (unused when n_out == 0)
@@ -88,17 +90,22 @@ struct V3Tail {
 inline V3Tail v3_tail(const V3Args& a) {
     return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps};
 }
-// 13 dwords (14 user SGPRs are available for preloading next to the kernarg pointer): grid size | rs_cap << 24 and
-// sets_q | sets_r << 16 share a dword each (nblk, sets_r < 65536: gemv_v3_launch checks)
-#define V3_KERNEL_ARGS(a) (a).qw, (a).x, (a).szp, (a).ow, (a).g.K, (a).g.nfull, (a).g.ngroups, \
-    (uint32_t)(a).nblk | ((uint32_t)(a).rs_cap << 24), (uint32_t)(a).sets_q | ((uint32_t)(a).sets_r << 16), qeft::v3_tail(a)
+// 13 dwords (14 user SGPRs are available for preloading next to the kernarg pointer): five pointers, K, and two packed words:
+// nblk | rs_cap << 16 | per-channel << 24 | xn << 25 and sets_q | sets_r << 16 (nblk, sets_r < 65536: gemv_v3_launch checks);
+// the step and group counts follow from K and the flags
+#define V3_KERNEL_ARGS(a) (a).qw, (a).x, (a).szp, (a).ow, (a).xn_gamma, (a).g.K, \
+    (uint32_t)(a).nblk | ((uint32_t)(a).rs_cap << 16) | ((a).g.ngroups == 1 && (a).g.K > 128 ? 1u << 24 : 0u) | ((a).xn_gamma ? 1u << 25 : 0u), \
+    (uint32_t)(a).sets_q | ((uint32_t)(a).sets_r << 16), qeft::v3_tail(a)
 
 // ---- LDS carve-up (bytes); every DMA-filled region is a whole number of 1 KB pieces
 __host__ __device__ constexpr int v3_x_bytes(int K) { return (K * 2 + 1023) / 1024 * 1024; }
 __host__ __device__ constexpr int v3_sz_bytes(int ngroups) { return (ngroups * 64 + 1023) / 1024 * 1024; }   // per row set
-__host__ __device__ constexpr size_t v3_smem_bytes(int K, int ngroups, int n_out, int rs_cap) {
+__host__ __device__ constexpr int v3_xf_bytes(int K) { return (K * 4 + 1023) / 1024 * 1024; }   // fp32 h of an xn launch
+__host__ __device__ constexpr size_t v3_red_bytes(int rs_cap) { return ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024; }
+__host__ __device__ constexpr size_t v3_smem_bytes(int K, int ngroups, int n_out, int rs_cap, bool xn = false) {
     return (size_t)v3_x_bytes(K) + (size_t)rs_cap * v3_sz_bytes(ngroups) + (n_out > 0 ? (size_t)rs_cap * 4096 : 0) +
-           1024 /* epilogue operands */ + 2048 /* ssq_in */ + (size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64;
+           1024 /* epilogue operands */ + 2048 /* ssq_in */ + v3_red_bytes(rs_cap) +
+           (xn ? (size_t)v3_xf_bytes(K) + v3_x_bytes(K) : 0);      /* xn: fp32 h + its gamma, behind everything else */
 }
 
 // ---- source byte offsets of every load (relative to the operand's base)
@@ -111,6 +118,11 @@ __host__ __device__ inline uint32_t v3_last_step_off(const V3Geom& G) { return (
 // x piece i: the lane's 16 source bytes, clamped (the LDS destination is lane-linear; clamped lanes fill padding)
 __host__ __device__ inline uint32_t v3_x_off(const V3Geom& G, int piece, int lane) {
     const uint32_t o = (uint32_t)piece * 1024u + (uint32_t)lane * 16u, last = (uint32_t)G.K * 2u - 16u;
+    return o < last ? o : last;
+}
+// xn launches: piece i of the fp32 vector h (K * 4 bytes); its gamma uses v3_x_off
+__host__ __device__ inline uint32_t v3_xf_off(const V3Geom& G, int piece, int lane) {
+    const uint32_t o = (uint32_t)piece * 1024u + (uint32_t)lane * 16u, last = (uint32_t)G.K * 4u - 16u;
     return o < last ? o : last;
 }
 // scale piece j of set g: the set's words are one contiguous run of ngroups * 64 bytes
@@ -158,14 +170,15 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
 // wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
 template <int NW, int D, bool OUTL, int MODE, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
-                                                          int K_, int nfull_, int ngroups_, uint32_t nblk_rscap, uint32_t setsq_setsr,
+                                                          const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
     static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
     // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
     // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
     // dependent scalar-memory round trip in the middle of the stream
-    V3Geom G{K_, a.n_out, a.nsteps, nfull_, ngroups_, a.nsets};
-    const int nblk = (int)(nblk_rscap & 0xffffffu), rs_cap = (int)(nblk_rscap >> 24);
+    const bool per_channel_f = (nblk_rscap_flags >> 24) & 1u, XN = (nblk_rscap_flags >> 25) & 1u;
+    V3Geom G{K_, a.n_out, a.nsteps, (K_ >> 7) - (OUTL ? 1 : 0), per_channel_f ? 1 : (K_ >> 7), a.nsets};
+    const int nblk = (int)(nblk_rscap_flags & 0xffffu), rs_cap = (int)((nblk_rscap_flags >> 16) & 0xffu);
     const int sets_q = (int)(setsq_setsr & 0xffffu), sets_r = (int)(setsq_setsr >> 16);
     const int ssq_n = a.n_ssq_in;
     const float eps = a.eps;
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     const uint8_t* const residual = (const uint8_t*)a.residual;
     const uint8_t* const gamma_out = (const uint8_t*)a.gamma_out;
     asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(rs_cap), "s"(nblk), "s"(sets_q), "s"(sets_r), "s"(xptr), "s"(qw),
-                 "s"(szp), "s"(ow));
+                 "s"(szp), "s"(ow), "s"(xn_gamma));
 
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
     const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups);
@@ -189,6 +202,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     uint8_t* epl = owl + (OUTL ? rs_cap * 4096 : 0);                  // [64 lanes][16 B]: residual | gamma_out of the block's rows
     float* ssql = (float*)(epl + 1024);                               // [512] ssq_in
     float* red = ssql + V3_MAX_SSQ;                                   // [rs_cap][NW][16]
+    uint8_t* xf = (uint8_t*)red + v3_red_bytes(rs_cap);               // xn launches: [K] fp32 h, then its gamma [K] fp16
+    uint8_t* xg = xf + v3_xf_bytes(G.K);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -203,8 +218,19 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
     //         wait for until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
     const int PX = XB >> 10, SPS = SZB >> 10;
-    for (int p = wave; p < PX; p += NW)
-        v3_dma16(xptr + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 10)));
+    if (!XN) {
+        for (int p = wave; p < PX; p += NW)
+            v3_dma16(xptr + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 10)));
+    } else {               // fp32 h (2 PX pieces) and its gamma (PX pieces) go to their own regions; xs is written in step 3b
+        const int PF = v3_xf_bytes(G.K) >> 10;
+        for (int p = wave; p < PF + PX; p += NW) {
+            if (p < PF)
+                v3_dma16(xptr + v3_xf_off(G, p, lane), __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xf + ((uint32_t)p << 10)));
+            else
+                v3_dma16((const uint8_t*)xn_gamma + v3_x_off(G, p - PF, lane),
+                         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xg + ((uint32_t)(p - PF) << 10)));
+        }
+    }
     for (int rs = 0; rs < RS; ++rs) {
         for (int j = wave; j < SPS; j += NW)
             v3_dma16(szp + v3_sz_off(G, set0 + rs, j, lane),
@@ -259,6 +285,25 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // ---- 3b. xn launches: xs = fp16(h * gamma) (the producers' rounding, qeft_residual_norm), sum of h^2 per wave -> LDS.
+    //          This runs while the first weight loads are still on their way.
+    float xn_ss = 0.f;
+    if (XN) {
+        for (int e = tid * 4; e < G.K; e += NW * 64 * 4) {
+            const f32x4 hv = *(const f32x4*)(xf + (size_t)e * 4);
+            const h4 gv = *(const h4*)(xg + (size_t)e * 2);
+            h4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (f16)(hv[j] * (float)gv[j]);
+                xn_ss += hv[j] * hv[j];
+            }
+            *(h4*)(xs + (size_t)e * 2) = o;
+        }
+        xn_ss = wave_sum(xn_ss);
+        if (lane == 0) ssql[wave] = xn_ss;             // the ssq_in region is free in an xn launch
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: __syncthreads() would drain the ring
+    }
     if (ABL & 8) ts[2] = wall_clock64();
 
     // ---- 4. steps.  acc[rs]: lanes kc == 0 hold row nl of row set rs (batch row 0 = D row 0, register 0)
@@ -405,7 +450,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     __syncthreads();
     if (ABL & 8) ts[5] = wall_clock64();
     float rs_norm = 1.f;
-    if (ssq_in) {               // every wave sums the (<= 512) partials itself, in a fixed order: no second barrier
+    if (XN) {
+        float sx = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sx += ssql[w];
+        rs_norm = __builtin_amdgcn_rsqf(sx * (1.f / (float)G.K) + eps);
+    } else if (ssq_in) {               // every wave sums the (<= 512) partials itself, in a fixed order: no second barrier
         // two unconditional 16-byte reads per lane (a guarded read is a branch with its own wait); what lies past the array
         // is dropped by a select, never added.  The wave sum is DPP + readlane (qeft_common.h): with eight guarded reads and
         // a shuffle butterfly this block cost 0.5 us of every q|k|v and gate|up launch

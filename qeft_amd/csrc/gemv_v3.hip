@@ -64,7 +64,7 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     a.nblk = nblk;
     a.sets_q = a.g.nsets / nblk;
     a.sets_r = a.g.nsets % nblk;
-    const size_t smem = v3_smem_bytes(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap);
+    const size_t smem = v3_smem_bytes(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.xn_gamma != nullptr);
     if (smem > 160 * 1024 || nblk >= 65536) return hipErrorInvalidValue;       // (nblk, sets_r share dwords with rs_cap, sets_q)
     // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
     static const int f_nw = env_int("QEFT_GEMV_NW"), f_d = env_int("QEFT_GEMV_DEPTH");     // lab overrides
@@ -83,7 +83,7 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
 // Walks all blocks x waves x lanes x {staging pieces, ring issues incl. the clamped ones past the end, epilogue operands,
 // output rows} with the SAME __host__ __device__ functions the kernel uses and counts accesses that leave their operand.
 // n_rows_have: the number of rows the operands really hold (== G.nsets * 16 unless the caller is the negative control).
-long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in) {
+long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn) {
     long long bad = 0;
     const size_t qw_bytes = (size_t)(n_rows_have / 4) * G.K * 2, sz_bytes = (size_t)(n_rows_have / 16) * G.ngroups * 64,
                  ow_bytes = (size_t)n_rows_have * 128 * 2, res_bytes = (size_t)n_rows_have * 4, gam_bytes = (size_t)n_rows_have * 2;
@@ -95,7 +95,9 @@ long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq
         if (RS < 1 || RS > V3_MAX_RS || set0 < 0 || set0 + RS > G.nsets) { ++bad; continue; }
         for (int lane = 0; lane < 64; ++lane) {
             const int nl = lane & 15, kc = lane >> 4;
-            for (int p = 0; p < (XB >> 10); ++p) bad += (size_t)v3_x_off(G, p, lane) + 16 > (size_t)G.K * 2;
+            for (int p = 0; p < (XB >> 10); ++p) bad += (size_t)v3_x_off(G, p, lane) + 16 > (size_t)G.K * 2;      // x, or an xn launch's gamma
+            if (xn)
+                for (int p = 0; p < (v3_xf_bytes(G.K) >> 10); ++p) bad += (size_t)v3_xf_off(G, p, lane) + 16 > (size_t)G.K * 4;
             bad += v3_epi_off(set0, RS, lane) + 16 > (lane < 16 ? res_bytes : gam_bytes);
             if (n_ssq_in > 0)
                 for (int w = 2; w < 4; ++w)

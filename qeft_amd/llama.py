@@ -657,32 +657,39 @@ class DecodeEngine:
 
     @torch.no_grad()
     def _launch_token_tp3(self, linears_only=False, only=None):
-        """One token of one tensor-parallel rank on the v3 GEMV: q|k|v -> attention (local heads, output scattered into
-        o_proj's x vector) -> o_proj partial (+ h32 on rank 0) -> all-reduce -> residual_norm -> gate|up (SiLU epilogue, output
-        straight into down_proj's x vector) -> down_proj partial (+ h32 on rank 0) -> all-reduce -> residual_norm."""
+        """One token of one tensor-parallel rank on the v3 GEMV: q|k|v (RMSNorm of the all-reduced h inside the launch) ->
+        attention (local heads, output scattered into o_proj's x vector) -> o_proj partial (+ h on rank 0) -> all-reduce ->
+        gate|up (norm inside, SiLU epilogue, output straight into down_proj's x vector) -> down_proj partial (+ h on rank 0)
+        -> all-reduce: 5 launches and 2 collectives per layer.  The fp32 residual stream alternates between two buffers
+        (a partial-output launch reads h from one and writes into the other, which the all-reduce then completes)."""
         s, lib, ck = self.m.shape, self.lib, _lib.check
         st = torch.cuda.current_stream(self.dev).cuda_stream
         g, no, eps = s.group_size, s.n_out, s.rms_eps
         layers = self.m.model.layers
-        xn, ssq, h32, part = self.xn.data_ptr(), self.ssq.data_ptr(), self.h32.data_ptr(), self.part32.data_ptr()
-        res_in = h32 if self.rank == 0 else self.zero32.data_ptr()
-        n_ssq = self.n_ssq_tb
+        cur, oth = self.h32, self.part32
+        zero = self.zero32.data_ptr()
 
-        def lin(op, x, y, mode=0, residual=None, ssq_in=None):
-            return lib.qeft_decode_linear(x, op.qweight.data_ptr(), op.sz_packed.data_ptr(),
-                                          op.oweight.data_ptr() if no else None, None, y, op.outfeatures, op.infeatures, g, no,
-                                          mode, residual, ssq_in, n_ssq if ssq_in else 0, eps, None, None, None, st)
+        def hnorm(op, h, gamma, y, mode=0):
+            return lib.qeft_decode_linear_hnorm(h.data_ptr(), gamma.data_ptr(), op.qweight.data_ptr(), op.sz_packed.data_ptr(),
+                                                op.oweight.data_ptr() if no else None, None, y, op.outfeatures, op.infeatures, g,
+                                                no, mode, eps, st)
 
-        def pick(tag):
-            return lin if only in (None, tag) else (lambda *a, **kw: 0)
+        def partial(op, x, h, y):           # y (fp32) = op . x + (rank 0: h)
+            return lib.qeft_decode_linear(x, op.qweight.data_ptr(), op.sz_packed.data_ptr(), op.oweight.data_ptr() if no else None,
+                                          None, y.data_ptr(), op.outfeatures, op.infeatures, g, no, 0,
+                                          h.data_ptr() if self.rank == 0 else zero, None, 0, eps, None, None, None, st)
+
+        def pick(tag, fn):
+            return fn if only in (None, tag) else (lambda *a, **kw: 0)
         if not linears_only:
             ck(lib.qeft_token_begin_norm(self.m.model.embed_tokens.weight.data_ptr(), self.tok.data_ptr(),
-                                         self.rope_tab.data_ptr(), self.pos.data_ptr(), h32, self.rope_row.data_ptr(),
-                                         layers[0].input_layernorm.data_ptr(), xn, ssq, s.hidden, s.vocab, s.max_seq, st))
+                                         self.rope_tab.data_ptr(), self.pos.data_ptr(), cur.data_ptr(), self.rope_row.data_ptr(),
+                                         layers[0].input_layernorm.data_ptr(), self.xn.data_ptr(), self.ssq.data_ptr(), s.hidden,
+                                         s.vocab, s.max_seq, st))
         qp = self.qkv_loc.data_ptr()
         for li, L in enumerate(layers):
             pk = self.tp3ops[li]
-            ck(pick("qkv")(pk["qkv"], xn, qp, ssq_in=ssq))
+            ck(pick("qkv", hnorm)(pk["qkv"], cur, L.input_layernorm, qp))
             if not linears_only:
                 ck(lib.qeft_rope_attn_decode(qp, qp + self.hs * 2, qp + (self.hs + self.kvs) * 2,
                                              self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
@@ -690,19 +697,18 @@ class DecodeEngine:
                                              pk["att_pos"].data_ptr(), pk["x_o"].data_ptr(),
                                              self.attn_ws.data_ptr() if self.attn_ws is not None else None,
                                              self.attn_split, self.heads_l, self.kv_heads_l, s.max_seq, st))
-            ck(pick("o")(pk["o"], pk["x_o"].data_ptr(), part, residual=res_in))
+            ck(pick("o", partial)(pk["o"], pk["x_o"].data_ptr(), cur, oth))
             if not linears_only:
-                self._all_reduce(self.part32)
-                ck(lib.qeft_residual_norm(part, None, L.post_attention_layernorm.data_ptr(), h32, xn, ssq, s.hidden, st))
-            ck(pick("gu")(pk["gu"], xn, pk["x_d"].data_ptr() + pk["lead_d"] * 2, mode=1, ssq_in=ssq))
-            ck(pick("d")(pk["d"], pk["x_d"].data_ptr(), part, residual=res_in))
+                self._all_reduce(oth)
+            cur, oth = oth, cur
+            ck(pick("gu", hnorm)(pk["gu"], cur, L.post_attention_layernorm, pk["x_d"].data_ptr() + pk["lead_d"] * 2, mode=1))
+            ck(pick("d", partial)(pk["d"], pk["x_d"].data_ptr(), cur, oth))
             if not linears_only:
-                self._all_reduce(self.part32)
-                nxt = layers[li + 1].input_layernorm.data_ptr() if li + 1 < len(layers) else None
-                ck(lib.qeft_residual_norm(part, None, nxt, h32, xn if nxt else None, ssq if nxt else None, s.hidden, st))
+                self._all_reduce(oth)
+            cur, oth = oth, cur
         if linears_only:
             return
-        self._token_tail(h32, st)
+        self._token_tail(cur.data_ptr(), st)         # an even number of swaps: cur is self.h32 again
 
     def capture(self, linears_only=False, only=None, split=None):
         """Capture one token into a hipGraph (after a warm-up launch on a side stream, as torch requires).  `split`:

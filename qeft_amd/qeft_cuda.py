@@ -375,6 +375,21 @@ def decode_linear(x, op, mode=V3_PLAIN, residual=None, ssq_in=None, eps=0.0, gam
     return (y, y_norm, ssq) if gamma_out is not None else y
 
 
+def decode_linear_hnorm(h32, gamma, op, mode=V3_PLAIN, eps=1e-5, out=None):
+    """y = op . rmsnorm(h32) * gamma with the whole norm inside the launch (qeft_decode_linear_hnorm): h32 fp32 [K], gamma
+    fp16 [K]; y fp16 [N] (V3_PLAIN) or [N/2] (V3_PAIR, SiLU(gate) * up)."""
+    n, k, r = op.outfeatures, op.infeatures, op.outlierfeatures
+    _need(h32.dtype == torch.float32 and h32.numel() == k and gamma.dtype == torch.float16 and gamma.numel() == k,
+          "h32 must be float32 [K] and gamma float16 [K]")
+    y = out if out is not None else torch.empty(n // 2 if mode == V3_PAIR else n, dtype=torch.float16, device=h32.device)
+    with torch.cuda.device(h32.device):
+        _lib.check(_lib.lib().qeft_decode_linear_hnorm(h32.data_ptr(), gamma.data_ptr(), op.qweight.data_ptr(),
+                                                       op.sz_packed.data_ptr(), op.oweight.data_ptr() if r else None,
+                                                       op.bias.data_ptr() if op.bias is not None else None, y.data_ptr(), n, k,
+                                                       op.group_size, r, mode, eps, _stream(h32)))
+    return y
+
+
 def residual_norm(h32, add=None, gamma=None, out=None):
     """h_out (fp32) = h32 (+ add fp16); with gamma also (fp16(h_out * gamma), partial sums of h_out^2) (qeft_residual_norm)."""
     n = h32.numel()

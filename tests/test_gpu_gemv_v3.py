@@ -180,3 +180,35 @@ def test_fused_final_norm_lm_head(hidden, vocab):
     want = hn[0].double() @ w.double().t()
     assert torch.isfinite(logits).all()
     assert (logits.double() - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("n,k,pair", [(4096, 4096, False), (22016 // 2, 4096, True), (512, 1024, False), (1728, 5120, True), (48, 640, False)])
+def test_consumer_side_whole_rmsnorm(n, k, pair):
+    """qeft_decode_linear_hnorm: the launch normalises the fp32 vector itself == residual_norm producer + deferred-1/rms
+    consumer (same fp16(h * gamma) staging, another summation order of h^2) and the float64 chain."""
+    from qeft_amd import fuse, qeft_cuda
+    r, g, eps = 128, 128, 1e-5
+    rng = np.random.default_rng(n + k)
+    h = (rng.standard_normal(k) * 2).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(k)).astype(np.float16)
+    ht, gt = torch.from_numpy(h).to(DEV), torch.from_numpy(gamma).to(DEV)
+    if pair:
+        (lg, bg), (lu, bu) = make(n, k, r, g, seed=n), make(n, k, r, g, seed=n + 1)
+        op, mode = fuse.pair_interleave(lg, lu), qeft_cuda.V3_PAIR
+    else:
+        l, b = make(n, k, r, g, seed=n)
+        op, mode = fuse.single(l), qeft_cuda.V3_PLAIN
+    y = qeft_cuda.decode_linear_hnorm(ht, gt, op, mode=mode, eps=eps)
+    _, hn, ssq = qeft_cuda.residual_norm(ht, None, gt)
+    y2 = qeft_cuda.decode_linear(hn, op, mode=mode, ssq_in=ssq, eps=eps)
+    torch.cuda.synchronize()
+    assert y.shape == y2.shape
+    assert (y.float() - y2.float()).abs().max().item() <= 2e-3 * y2.float().abs().max().item()
+    xn = h.astype(np.float64) / np.sqrt((h.astype(np.float64) ** 2).mean() + eps) * gamma.astype(np.float64)
+    if pair:
+        wg = O.dequant_dense(bg["qweight"], bg["scales"], bg["scaled_zeros"], bg["oweight"], g).astype(np.float64) @ xn
+        wu = O.dequant_dense(bu["qweight"], bu["scales"], bu["scaled_zeros"], bu["oweight"], g).astype(np.float64) @ xn
+        want = wg / (1 + np.exp(-wg)) * wu
+    else:
+        want = O.dequant_dense(b["qweight"], b["scales"], b["scaled_zeros"], b["oweight"], g).astype(np.float64) @ xn
+    assert rel_err(y.cpu().numpy(), want) < 3e-3

@@ -1,5 +1,5 @@
 """Tensor-parallel decode engine (Megatron pairing: q|k|v and gate|up by rows, o_proj and down_proj by columns, one fp32
-all-reduce after each of the two, llama.py).  On the real collective library (RCCL) a group of ONE rank runs exactly the
+all-reduce after each of the two, the consumers' RMSNorm inside their own launches, llama.py).  On the real collective library (RCCL) a group of ONE rank runs exactly the
 launch sequence of the multi-GPU bench, hipGraph capture of the collectives included; ranks > 1 run as threads of one
 process in lock step on the one GPU.  The sharded sum adds the K shards' fp32 partial outputs in rank order, so results
 equal the single-GPU engine to rounding, not bit for bit: the tolerance below is 2e-3 of the largest logit.  The sharding
