@@ -2,7 +2,7 @@
 all-reduce after each of the two, the consumers' RMSNorm inside their own launches, llama.py).  On the real collective library (RCCL) a group of ONE rank runs exactly the
 launch sequence of the multi-GPU bench, hipGraph capture of the collectives included; ranks > 1 run as threads of one
 process in lock step on the one GPU.  The sharded sum adds the K shards' fp32 partial outputs in rank order, so results
-equal the single-GPU engine to rounding, not bit for bit: the tolerance below is 2e-3 of the largest logit.  The sharding
+equal the single-GPU engine to rounding, not bit for bit: the tolerance below is 1e-3 of the largest logit.  The sharding
 arithmetic alone is covered on CPU with gloo (tests/test_tp_shards_cpu.py)."""
 import os
 import socket
@@ -42,7 +42,7 @@ def test_tp_engine_group_of_one_equals_single_gpu_engine(world_of_one, use_graph
     assert eng.tp and eng.P == 1 and eng.tp3
     got = eng.teacher_forced_logits(tokens)
     assert torch.isfinite(got).all()
-    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
     assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
     if not use_graph:
         assert eng.n_collectives == 2 * shape.n_layers          # one all-reduce after o_proj, one after down_proj
@@ -126,7 +126,7 @@ def test_tp_engine_two_ranks_in_lockstep_equal_single_gpu_engine(world):
     for r in range(world):
         assert outs[r] is not None and torch.isfinite(outs[r]).all()
         assert torch.equal(outs[r], outs[0]), f"rank {r} of {world} disagrees with rank 0"     # every rank holds the same sums
-        assert (outs[r] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), f"rank {r} of {world}"
+        assert (outs[r] - ref).abs().max().item() <= 1e-3 * ref.abs().max().item(), f"rank {r} of {world}"
         assert engines[r].n_collectives == 2 * shape.n_layers
     assert (outs[0].argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
 
@@ -168,4 +168,4 @@ def test_tp_engine_7b_13b_layer_shapes_in_lockstep(world, dims):
     torch.cuda.synchronize()
     for r in range(world):
         assert torch.equal(outs[r], outs[0])
-        assert (outs[r] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        assert (outs[r] - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()

@@ -1,7 +1,7 @@
 """The tensor-parallel engine as REAL processes: two ranks (one process each, as `bench.py --gpus 2` launches them) share
 the one GPU of the box and reduce over gloo -- torch.distributed's all_reduce on device tensors in place of RCCL, the rest
 of the path identical (shard construction per rank, 2 collectives per layer, replicated norms / lm_head).  Every rank's
-teacher-forced logits must equal the other's bit for bit and the single-GPU engine's within 2e-3 of the largest logit."""
+teacher-forced logits must equal the other's bit for bit and the single-GPU engine's within 1e-3 of the largest logit."""
 import os
 import socket
 
@@ -54,4 +54,4 @@ def test_two_rank_processes_on_one_gpu_match_the_single_gpu_engine():
     (_, got0, ref, n0), (_, got1, _, n1) = res
     assert torch.isfinite(got0).all() and torch.equal(got0, got1)
     assert n0 == n1 == 2 * 2                                   # 2 collectives per layer, 2 layers
-    assert (got0 - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (got0 - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
