@@ -201,6 +201,12 @@ int qeft_decode_linear(const void* x, const void* qweight, const void* sz_packed
                        void* y, int n, int k, int group_size, int n_out, int mode, const void* residual,
                        const float* ssq_in, int n_ssq_in, float eps, const void* gamma_out, void* y_norm, float* ssq_out,
                        qeft_stream_t stream);
+/* qeft_decode_linear_w3: qeft_decode_linear on the 3-bit EXTENSION layout (qweight3 int32 [n/16, ((k - n_out)/128) * 192],
+ * see below): 12 bytes per lane and step, every 3-bit field shifted down to bits 0..2 in registers (x stays raw). */
+int qeft_decode_linear_w3(const void* x, const void* qweight3, const void* sz_packed, const void* oweight, const void* bias,
+                          void* y, int n, int k, int group_size, int n_out, int mode, const void* residual,
+                          const float* ssq_in, int n_ssq_in, float eps, const void* gamma_out, void* y_norm, float* ssq_out,
+                          qeft_stream_t stream);
 /* qeft_decode_linear_hnorm: the same launch with the WHOLE RMSNorm on the consumer -- x is the fp32 vector h [k]; the launch
  * stages fp16(h * gamma_x) (the producers' rounding) and multiplies its row sums by rsqrt(mean(h^2) + eps).  For inputs that
  * no GEMV epilogue produced: the tensor-parallel path's h comes out of an all-reduce (qeft_amd/llama.py).  y fp16 (mode 0: [n],

@@ -49,6 +49,7 @@ SIGNATURES = {
     "qeft_token_end": [_p, _p, _p, _i, _i, _p],
     "qeft_decode_linear_blocks": [_i],
     "qeft_decode_linear": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, ctypes.c_float, _p, _p, _p, _p],
+    "qeft_decode_linear_w3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, ctypes.c_float, _p, _p, _p, _p],
     "qeft_gemv_v3_check_extents": [_i, _i, _i, _i, _i, _i],
     "qeft_decode_linear_hnorm": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, ctypes.c_float, _p],
     "qeft_token_begin_norm_blocks": [_i],

@@ -10,7 +10,7 @@ namespace qeft {
 hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st);
 int gemv_v3_blocks(int nsets);
 bool gemv_v3_ok(int K, int G, int n_out);
-long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn);
+long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn, int bits);
 hipError_t token_begin_norm_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
                                    void* rope_row, const void* gamma, void* hnorm, float* ssq_out, int hidden, int vocab,
                                    int max_seq, hipStream_t st);
@@ -519,6 +519,36 @@ int qeft_decode_linear(const void* x, const void* qweight, const void* sz_packed
     return finish(qeft::gemv_v3_launch(a, mode, (hipStream_t)stream));
 }
 
+int qeft_decode_linear_w3(const void* x, const void* qweight3, const void* sz_packed, const void* oweight, const void* bias,
+                       void* y, int n, int k, int group_size, int n_out, int mode, const void* residual,
+                       const float* ssq_in, int n_ssq_in, float eps, const void* gamma_out, void* y_norm, float* ssq_out,
+                       qeft_stream_t stream) {
+    if (!x || !qweight3 || !sz_packed || !y || (n_out > 0 && !oweight)) return QEFT_ERR_NULL;
+    if (!aligned16(x) || ((uintptr_t)qweight3 & 3) != 0 || !aligned16(sz_packed) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
+    qeft::V3Args a{};
+    if (int e = v3_geom(a.g, n, k, group_size, n_out, mode)) return e;
+    if ((residual || gamma_out) && mode != qeft::V3_MODE_PLAIN) return QEFT_ERR_SHAPE;
+    if (gamma_out && (!residual || !y_norm || !ssq_out)) return QEFT_ERR_NULL;
+    if ((residual && !aligned16(residual)) || (gamma_out && !aligned16(gamma_out))) return QEFT_ERR_ALIGN;
+    if (ssq_in && (n_ssq_in < 1 || n_ssq_in > qeft::V3_MAX_SSQ || !aligned16(ssq_in))) return QEFT_ERR_SHAPE;
+    a.x = (const qeft::f16*)x;
+    a.qw = (const uint8_t*)qweight3;
+    a.bits = 3;
+    a.szp = (const uint8_t*)sz_packed;
+    a.ow = (const uint8_t*)oweight;
+    a.bias = (const qeft::f16*)bias;
+    a.residual = (const float*)residual;
+    a.y = residual ? nullptr : (qeft::f16*)y;
+    a.y32 = residual ? (float*)y : nullptr;
+    a.ssq_in = ssq_in;
+    a.n_ssq_in = ssq_in ? n_ssq_in : 0;
+    a.eps = eps;
+    a.gamma_out = (const qeft::f16*)gamma_out;
+    a.ynorm = (qeft::f16*)y_norm;
+    a.ssq_out = ssq_out;
+    return finish(qeft::gemv_v3_launch(a, mode, (hipStream_t)stream));
+}
+
 int qeft_decode_linear_hnorm(const void* h32, const void* gamma_x, const void* qweight, const void* sz_packed, const void* oweight,
                              const void* bias, void* y, int n, int k, int group_size, int n_out, int mode, float eps,
                              qeft_stream_t stream) {
@@ -542,7 +572,8 @@ long long qeft_gemv_v3_check_extents(int n, int k, int group_size, int n_out, in
     qeft::V3Geom G{};
     if (v3_geom(G, n, k, group_size, n_out, qeft::V3_MODE_PLAIN) != QEFT_OK) return -1;
     if (n_ssq_in < 0 || n_ssq_in > qeft::V3_MAX_SSQ) return -1;
-    return qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in, n_ssq_in == 0);
+    return qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in, n_ssq_in == 0, 4) +
+           (G.nfull > 0 ? qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in, false, 3) : 0);
 }
 
 int qeft_token_begin_norm_blocks(int hidden) { return hidden >= 8 ? qeft::token_begin_norm_blocks(hidden) : 0; }

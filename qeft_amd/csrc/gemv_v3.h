@@ -68,6 +68,7 @@ struct V3Args {
     f16* ynorm;
     float* ssq_out;
     long long* dbg;         // lab only (ABL & 8): per block 8 x 100 MHz time stamps of wave 0; never read in the product
+    int bits;               // 4 (0 is taken as 4), or 3: qw is the 3-bit extension layout int32 [N/16][nfull * 192]
 };
 
 // What the kernel receives.  The first 16 dwords of the kernel-argument segment -- the four operand pointers and the
@@ -115,6 +116,10 @@ __host__ __device__ inline uint32_t v3_w_lane_off(const V3Geom& G, int nl, int k
     return (uint32_t)(nl >> 2) * (uint32_t)G.K * 2u + (uint32_t)(kc >> 1) * 128u + (uint32_t)(nl & 3) * 32u + (uint32_t)(kc & 1) * 16u;
 }
 __host__ __device__ inline uint32_t v3_last_step_off(const V3Geom& G) { return (uint32_t)G.K * 2u - 256u; }
+// 3-bit extension layout (oracle.pack_w3): int32 [N/16][nfull][64 lanes][3] -- a 16-row x 128-k step is 768 contiguous bytes,
+// lane L = (row L & 15, 32-k chunk L >> 4) holds 12 of them; a row set is nfull consecutive steps
+__host__ __device__ inline size_t v3w3_set_off(const V3Geom& G, int g) { return (size_t)g * G.nfull * 768; }
+__host__ __device__ inline uint32_t v3w3_last_step_off(const V3Geom& G) { return (uint32_t)(G.nfull > 0 ? G.nfull - 1 : 0) * 768u; }
 // x piece i: the lane's 16 source bytes, clamped (the LDS destination is lane-linear; clamped lanes fill padding)
 __host__ __device__ inline uint32_t v3_x_off(const V3Geom& G, int piece, int lane) {
     const uint32_t o = (uint32_t)piece * 1024u + (uint32_t)lane * 16u, last = (uint32_t)G.K * 2u - 16u;
@@ -168,11 +173,12 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
 
 // NW waves per block (8, or 16 for launches of one block per CU: twice the instruction streams per SIMD for the same bytes);
 // wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
-template <int NW, int D, bool OUTL, int MODE, int ABL = 0>
+template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4>
 __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
     static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
+    static_assert(BITS == 4 || BITS == 3, "4-bit checkpoint layout or the 3-bit extension layout (oracle: pack_w3)");
     // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
     // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
     // dependent scalar-memory round trip in the middle of the stream
@@ -244,20 +250,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     //         t = 0 .. nsw*RS-1 of (step wave + NW (t / RS), row set t % RS): STEP-major, so the x fragments and the bias
     //         sums of a step are fetched / computed once and serve all RS row sets.  Issues past the end re-read a valid address.
     const int nsw = (G.nfull - wave + NW - 1) / NW;
-    const uint32_t set_bytes = (uint32_t)G.K * 8u;                   // one 16-row set = 4 row groups of 2 K bytes
-    const uint8_t* const wbase = qw + v3_w_set_off(G, set0);         // wave-uniform
-    const uint32_t lane_off = v3_w_lane_off(G, nl, kc);
-    const uint32_t step0 = min((uint32_t)wave * 256u, v3_last_step_off(G));
-    u32x4 ring[D];
+    constexpr uint32_t STEPB = BITS == 3 ? 768u : 256u;              // bytes from one 128-k step of a row (group) to the next
+    const uint32_t set_bytes = BITS == 3 ? (uint32_t)G.nfull * 768u : (uint32_t)G.K * 8u;   // one 16-row set
+    const uint8_t* const wbase = qw + (BITS == 3 ? v3w3_set_off(G, set0) : v3_w_set_off(G, set0));         // wave-uniform
+    const uint32_t lane_off = BITS == 3 ? (uint32_t)lane * 12u : v3_w_lane_off(G, nl, kc);
+    const uint32_t step0 = min((uint32_t)wave * STEPB, BITS == 3 ? v3w3_last_step_off(G) : v3_last_step_off(G));
+    typedef typename std::conditional<BITS == 3, u32x3_u, u32x4>::type ring_t;
+    ring_t ring[D];
     int p_rs = 0, p_i = 0;
     uint32_t p_off = step0;                                          // uniform byte offset of the next issue
-    auto issue = [&](u32x4& b) {
-        b = __builtin_nontemporal_load((const u32x4*)(wbase + p_off + lane_off));
+    auto issue = [&](ring_t& b) {
+        b = __builtin_nontemporal_load((const ring_t*)(wbase + p_off + lane_off));
         p_off += set_bytes;
         if (++p_rs >= RS) {                                          // next step (or, past the end, the last one again)
             p_rs = 0;
             if (p_i + 1 < nsw) ++p_i;
-            p_off = step0 + (uint32_t)p_i * (NW * 256u);
+            p_off = step0 + (uint32_t)p_i * (NW * STEPB);
         }
     };
 #pragma unroll
@@ -355,8 +363,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
             f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[1], c8, z4, 0, 0, 0);
             A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, A0, 0, 0, 0);
             A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[3], c8, A1, 0, 0, 0);
-            lo = A0[0];
-            hi = A1[0];
+            if (BITS == 3) {                // one scale class: every 3-bit field is moved to bits 0..2 of its half-word
+                lo = A0[0] + A1[0];
+                hi = 0.f;
+            } else {
+                lo = A0[0];
+                hi = A1[0];
+            }
         };
         load_x(xf, 0);
         uint32_t szw = scale_word(0, 0);
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
             acc2 = fmaf(add, pv_f2, acc2);
             acc3 = fmaf(add, pv_f3, acc3);
         };
-        auto consume = [&](const u32x4& wv) {
+        auto consume = [&](const ring_t& wv) {
             const bool last_rs = c_rs + 1 >= RS;
             const int ni = c_i + 1 < nsw ? c_i + 1 : c_i;
             if (c_rs == 0) load_x(xn, ni);     // next step's fragments: in flight during this step's RS row sets
@@ -384,17 +397,35 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
             float lo, hi;
             if (ABL & 4) {
                 lo = __builtin_bit_cast(float, wv[0] ^ wv[1]);
-                hi = __builtin_bit_cast(float, wv[2] ^ wv[3]);
+                hi = __builtin_bit_cast(float, wv[2] ^ wv[BITS == 3 ? 0 : 3]);
             } else {
                 // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
                 u32x4 bf[4];
+                if (BITS == 4) {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t v = wv[w], t = v >> 8;
-                    bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
-                    bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q
-                    bf[2][w] = (t & 0x000f000fu) | MAGIC;
-                    bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t v = wv[w], t = v >> 8;
+                        bf[0][w] = (v & 0x000f000fu) | MAGIC;    // 1024 + q
+                        bf[1][w] = (v & 0x00f000f0u) | MAGIC;    // 1024 + 16 q
+                        bf[2][w] = (t & 0x000f000fu) | MAGIC;
+                        bf[3][w] = (t & 0x00f000f0u) | MAGIC;
+                    }
+                } else {
+                    // 3-bit: pair e = 4 j + w (k = 2e, 2e + 1 of the lane's chunk, natural order) sits in word e / 5 at bits
+                    // 3 (e % 5) of each half-word, pair 15 in bits 15 / 31 of the three words.  x is consumed raw here, so every
+                    // field is shifted down to bits 0..2 (1024 + q for all of them: one scale class, no pre-scaled x)
+                    uint32_t ext[16];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const uint32_t v = wv[i];
+#pragma unroll
+                        for (int f = 0; f < 5; ++f) ext[5 * i + f] = ((v >> (3 * f)) & 0x00070007u) | MAGIC;
+                    }
+                    ext[15] = (((wv[0] >> 15) & 0x00010001u) | ((wv[1] >> 14) & 0x00020002u) | ((wv[2] >> 13) & 0x00040004u)) | MAGIC;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) bf[j][w] = ext[4 * j + w];
                 }
                 f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
                 f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
@@ -402,8 +433,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
                 if (last_rs) bias_sums(xn, nlo, nhi);      // the NEXT step's sums ride behind this step's last products
                 fold();                                     // the PREVIOUS (step, row set): its MFMAs retired long ago
-                lo = Plo[0];
-                hi = Phi[0];
+                if (BITS == 3) {
+                    lo = Plo[0] + Phi[0];
+                    hi = 0.f;
+                } else {
+                    lo = Plo[0];
+                    hi = Phi[0];
+                }
             }
             if (ABL & 4) fold();
             pv_lo = lo; pv_hi = hi; pv_alo = alo; pv_ahi = ahi; pv_szw = szw;

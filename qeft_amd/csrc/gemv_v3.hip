@@ -31,7 +31,7 @@ int gemv_v3_blocks(int nsets) {
 // What the v3 kernel takes: whole 128-k steps, the checkpoint's r = 128 (or no outlier slice), group 128 or per-channel.
 bool gemv_v3_ok(int K, int G, int n_out) { return K % 128 == 0 && K >= 128 && (n_out == 0 || (n_out == 128 && K > 128)) && (G == 128 || G == K); }
 
-template <int NW, int D, bool OUTL>
+template <int NW, int D, bool OUTL, int BITS>
 static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
     auto go = [&](auto kern) -> hipError_t {
         if (smem > 64 * 1024) {
@@ -41,16 +41,22 @@ static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hi
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
-    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN>);
+    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR, 0, BITS>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN, 0, BITS>);
 }
 
-template <int NW, bool OUTL>
+template <int NW, bool OUTL, int BITS>
 static hipError_t launch_d(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
-    if (depth == 2) return launch_dm<NW, 2, OUTL>(a, mode, nblk, smem, st);
-    if constexpr (NW == 8) {            // 16-wave blocks are capped at 128 VGPRs: depth 6 would spill (and has too few steps)
-        if (depth == 6) return launch_dm<NW, 6, OUTL>(a, mode, nblk, smem, st);
+    if (depth == 2) return launch_dm<NW, 2, OUTL, BITS>(a, mode, nblk, smem, st);
+    if constexpr (NW == 8 && BITS == 4) {      // 16-wave blocks are capped at 128 VGPRs: depth 6 would spill (and has too few steps)
+        if (depth == 6) return launch_dm<NW, 6, OUTL, BITS>(a, mode, nblk, smem, st);
     }
-    return launch_dm<NW, 4, OUTL>(a, mode, nblk, smem, st);
+    return launch_dm<NW, 4, OUTL, BITS>(a, mode, nblk, smem, st);
+}
+
+template <int BITS>
+static hipError_t launch_b(const V3Args& a, int mode, int nblk, size_t smem, int nw, int depth, hipStream_t st) {
+    if (nw == 16) return a.g.n_out > 0 ? launch_d<16, true, BITS>(a, mode, nblk, smem, depth, st) : launch_d<16, false, BITS>(a, mode, nblk, smem, depth, st);
+    return a.g.n_out > 0 ? launch_d<8, true, BITS>(a, mode, nblk, smem, depth, st) : launch_d<8, false, BITS>(a, mode, nblk, smem, depth, st);
 }
 
 static int env_int(const char* name) {
@@ -74,18 +80,18 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     const int steps16 = ceil_div(a.g.nfull, 16) * a.rs_cap;
     const int nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 && steps16 >= 4 ? 16 : 8);
     const int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : (nw == 16 || nblk > 256 ? 2 : 4);
-    g_last_variant = mode == V3_MODE_PAIR ? "gemv_v3_pair" : "gemv_v3";
-    if (nw == 16) return a.g.n_out > 0 ? launch_d<16, true>(a, mode, nblk, smem, depth, st) : launch_d<16, false>(a, mode, nblk, smem, depth, st);
-    return a.g.n_out > 0 ? launch_d<8, true>(a, mode, nblk, smem, depth, st) : launch_d<8, false>(a, mode, nblk, smem, depth, st);
+    const bool w3 = a.bits == 3;
+    g_last_variant = mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
+    return w3 ? launch_b<3>(a, mode, nblk, smem, nw, depth, st) : launch_b<4>(a, mode, nblk, smem, nw, depth, st);
 }
 
 // ---- host-side enumeration of every address the kernel can form for a configuration (no GPU involved).
 // Walks all blocks x waves x lanes x {staging pieces, ring issues incl. the clamped ones past the end, epilogue operands,
 // output rows} with the SAME __host__ __device__ functions the kernel uses and counts accesses that leave their operand.
 // n_rows_have: the number of rows the operands really hold (== G.nsets * 16 unless the caller is the negative control).
-long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn) {
+long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn, int bits) {
     long long bad = 0;
-    const size_t qw_bytes = (size_t)(n_rows_have / 4) * G.K * 2, sz_bytes = (size_t)(n_rows_have / 16) * G.ngroups * 64,
+    const size_t qw_bytes = bits == 3 ? (size_t)(n_rows_have / 16) * G.nfull * 768 : (size_t)(n_rows_have / 4) * G.K * 2, sz_bytes = (size_t)(n_rows_have / 16) * G.ngroups * 64,
                  ow_bytes = (size_t)n_rows_have * 128 * 2, res_bytes = (size_t)n_rows_have * 4, gam_bytes = (size_t)n_rows_have * 2;
     const int nblk = gemv_v3_blocks(G.nsets);
     const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups);
@@ -115,12 +121,15 @@ long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq
             for (int NW = 8; NW <= 16; NW += 8)        // both instantiations of the kernel
                 for (int wave = 0; wave < NW; ++wave) {
                     const int nsw = (G.nfull - wave + NW - 1) / NW;
-                    uint32_t step0 = (uint32_t)wave * 256u;
-                    if (step0 > v3_last_step_off(G)) step0 = v3_last_step_off(G);
+                    const uint32_t stepb = bits == 3 ? 768u : 256u, last = bits == 3 ? v3w3_last_step_off(G) : v3_last_step_off(G);
+                    uint32_t step0 = (uint32_t)wave * stepb;
+                    if (step0 > last) step0 = last;
+                    const size_t set_off = bits == 3 ? v3w3_set_off(G, set0) : v3_w_set_off(G, set0);
+                    const size_t set_bytes = bits == 3 ? (size_t)G.nfull * 768 : (size_t)G.K * 8;
+                    const uint32_t lane_off = bits == 3 ? (uint32_t)lane * 12u : v3_w_lane_off(G, nl, kc);
                     for (int rs = 0; rs < RS; ++rs)
                         for (int i = 0; i < (nsw > 0 ? nsw : 1); ++i)
-                            bad += v3_w_set_off(G, set0) + (size_t)rs * G.K * 8 + step0 + (size_t)i * NW * 256 +
-                                   v3_w_lane_off(G, nl, kc) + 16 > qw_bytes;
+                            bad += set_off + (size_t)rs * set_bytes + step0 + (size_t)i * NW * stepb + lane_off + (bits == 3 ? 12 : 16) > qw_bytes;
                 }
         }
     }

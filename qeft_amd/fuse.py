@@ -14,11 +14,15 @@ from types import SimpleNamespace
 import torch
 
 
-def _operand(qweight, sz_packed, oweight, bias, n, k, g, r):
+def _operand(qweight, sz_packed, oweight, bias, n, k, g, r, bits=4):
     return SimpleNamespace(qweight=qweight.contiguous(), sz_packed=sz_packed.contiguous(),
                            oweight=oweight.contiguous() if oweight is not None else None,
                            bias=bias.contiguous() if bias is not None else None,
-                           outfeatures=n, infeatures=k, group_size=g, outlierfeatures=r)
+                           outfeatures=n, infeatures=k, group_size=g, outlierfeatures=r, bits=bits)
+
+
+def _bits(l):
+    return getattr(l, "bits", 4)
 
 
 def _plain_oweight(l):
@@ -35,7 +39,7 @@ def _szp(l):
 def _check(layers):
     l0 = layers[0]
     for l in layers:
-        assert (l.infeatures, l.group_size, l.outlierfeatures) == (l0.infeatures, l0.group_size, l0.outlierfeatures)
+        assert (l.infeatures, l.group_size, l.outlierfeatures, _bits(l)) == (l0.infeatures, l0.group_size, l0.outlierfeatures, _bits(l0))
         assert l.outfeatures % 16 == 0
         assert (l.bias is None) == (l0.bias is None)
     return l0.infeatures, l0.group_size, l0.outlierfeatures
@@ -44,7 +48,7 @@ def _check(layers):
 def single(layer):
     """One linear as a v3 operand (shares the module's buffers)."""
     k, g, r = _check([layer])
-    return _operand(layer.qweight, _szp(layer), _plain_oweight(layer) if r else None, layer.bias, layer.outfeatures, k, g, r)
+    return _operand(layer.qweight, _szp(layer), _plain_oweight(layer) if r else None, layer.bias, layer.outfeatures, k, g, r, _bits(layer))
 
 
 def concat_linears(layers):
@@ -53,7 +57,7 @@ def concat_linears(layers):
     return _operand(torch.cat([l.qweight for l in layers], 0), torch.cat([_szp(l) for l in layers], 0),
                     torch.cat([_plain_oweight(l) for l in layers], 0) if r else None,
                     torch.cat([l.bias for l in layers], 0) if layers[0].bias is not None else None,
-                    sum(l.outfeatures for l in layers), k, g, r)
+                    sum(l.outfeatures for l in layers), k, g, r, _bits(layers[0]))
 
 
 def pair_interleave(gate, up):
@@ -61,7 +65,14 @@ def pair_interleave(gate, up):
     k, g, r = _check([gate, up])
     n = gate.outfeatures
     assert up.outfeatures == n
-    qw = torch.cat([gate.qweight.view(n // 8, 2, -1), up.qweight.view(n // 8, 2, -1)], 1).reshape(n // 2, -1)
+    if _bits(gate) == 3:
+        # 3-bit layout int32 [n/16][steps][4 chunks][16 rows][3]: a lane record (row, chunk) is self-contained, so the
+        # interleave moves whole 12-byte records -- operand set i = rows 8i..8i+7 of gate (rows 0..7) and of up (rows 8..15)
+        steps = gate.qweight.shape[1] // 192
+        halves3 = lambda q: q.view(n // 16, steps, 4, 2, 8, 3).permute(0, 3, 1, 2, 4, 5).reshape(n // 8, steps, 4, 8, 3)   # noqa: E731
+        qw = torch.cat([halves3(gate.qweight), halves3(up.qweight)], 3).reshape(n // 8, steps * 192)
+    else:
+        qw = torch.cat([gate.qweight.view(n // 8, 2, -1), up.qweight.view(n // 8, 2, -1)], 1).reshape(n // 2, -1)
     sg, su = _szp(gate), _szp(up)                       # [n/16, groups, 16]
     ng = sg.shape[1]
     halves = lambda s: s.view(n // 16, ng, 2, 8).permute(0, 2, 1, 3).reshape(n // 8, ng, 8)   # noqa: E731
@@ -70,7 +81,7 @@ def pair_interleave(gate, up):
     bias = None
     if gate.bias is not None:
         bias = torch.cat([gate.bias.view(n // 8, 8), up.bias.view(n // 8, 8)], 1).reshape(2 * n)
-    return _operand(qw, szp, ow, bias, 2 * n, k, g, r)
+    return _operand(qw, szp, ow, bias, 2 * n, k, g, r, _bits(gate))
 
 
 def column_shard(layer, owned_cols):

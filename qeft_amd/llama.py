@@ -337,7 +337,7 @@ class DecodeEngine:
         # v3 path (single GPU, 4 bits, the shapes gemv_v3.h takes): raw-x GEMVs with the norms / SiLU on the producers'
         # epilogues and an fp32 residual stream.  QEFT_ENGINE_V2=1 keeps the round-1 launch sequence (A/B timing).
         g_, k_ok = s.group_size, (s.hidden % 128 == 0 and s.inter % 128 == 0)
-        self.v3 = (self.bits == 4 and not tp and k_ok and s.n_out in (0, 128) and g_ == 128 and s.hidden % 16 == 0
+        self.v3 = (self.bits in (3, 4) and not tp and k_ok and s.n_out in (0, 128) and g_ == 128 and s.hidden % 16 == 0
                    and s.inter % 16 == 0 and kvd % 16 == 0 and os.environ.get("QEFT_ENGINE_V2") != "1")
         self.tp3 = (tp and self.bits == 4 and k_ok and s.n_out in (0, 128) and g_ == 128 and self.hs % 16 == 0
                     and self.kvs % 16 == 0 and self.its % 16 == 0 and self.its >= 128
@@ -463,7 +463,7 @@ class DecodeEngine:
 
     def gemv_kernel_name(self):
         """The kernel(s) behind the quantized linears of a token (for bench.py's roofline record)."""
-        if self.bits == 3:
+        if self.bits == 3 and not self.v3:
             return "qeft::gemv_w4_mfma_group_kernel / gemv_w4_mfma_kernel <BITS = 3>"
         if self.v3 or self.tp3:
             return "qeft::gemv_v3_kernel"
@@ -622,8 +622,10 @@ class DecodeEngine:
         layers = self.m.model.layers
         xn, ssq, h32 = self.xn.data_ptr(), self.ssq.data_ptr(), self.h32.data_ptr()
 
+        entry = lib.qeft_decode_linear_w3 if self.bits == 3 else lib.qeft_decode_linear
+
         def lin(op, x, y, mode=0, residual=None, ssq_in=None, n_ssq=0, gamma_out=None):
-            return lib.qeft_decode_linear(x, op.qweight.data_ptr(), op.sz_packed.data_ptr(),
+            return entry(x, op.qweight.data_ptr(), op.sz_packed.data_ptr(),
                                           op.oweight.data_ptr() if no else None, None, y, op.outfeatures, op.infeatures, g, no,
                                           mode, residual, ssq_in, n_ssq, eps, gamma_out, xn if gamma_out else None,
                                           ssq if gamma_out else None, st)

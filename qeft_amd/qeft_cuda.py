@@ -339,8 +339,8 @@ def decode_linear(x, op, mode=V3_PLAIN, residual=None, ssq_in=None, eps=0.0, gam
     """y = Wdeq . x for one packed operand and the fp16 vector x[K], one launch of the v3 GEMV (qeft_decode_linear).
 
     op: an object with qweight / sz_packed / oweight (plain fp16 [n, r]) / bias / outfeatures / infeatures / group_size /
-        outlierfeatures -- a QuantLinear after set_kernel(), or a derived operand from qeft_amd.fuse (q|k|v concatenated,
-        gate|up pair-interleaved).
+        outlierfeatures (/ bits) -- a QuantLinear after set_kernel(), or a derived operand from qeft_amd.fuse (q|k|v
+        concatenated, gate|up pair-interleaved).  bits == 3: the 3-bit extension layout (qeft_decode_linear_w3).
     mode V3_PAIR: op is fuse.pair_interleave(gate, up) -> returns silu(gate) * up (fp16 [n/2]).
     residual (fp32 [n]): returns y32 = Wx + residual (fp32; `out` may alias residual for an in-place update).
     ssq_in (fp32 partial sums): x is (v * gamma) and ssq_in the partial sums of v^2: y is scaled by rsqrt(sum / K + eps).
@@ -364,8 +364,11 @@ def decode_linear(x, op, mode=V3_PLAIN, residual=None, ssq_in=None, eps=0.0, gam
     if gamma_out is not None:
         y_norm = torch.empty(n, dtype=torch.float16, device=dev)
         ssq = torch.zeros((decode_linear_blocks(n) + 3) // 4 * 4, dtype=torch.float32, device=dev)[:decode_linear_blocks(n)]
+    w3 = getattr(op, "bits", 4) == 3           # 3-bit extension layout: qweight int32 [n/16, ((k - r)/128) * 192]
+    _need(op.qweight.dtype == (torch.int32 if w3 else torch.int16), "qweight dtype does not match the operand's bit width")
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().qeft_decode_linear(
+        entry = _lib.lib().qeft_decode_linear_w3 if w3 else _lib.lib().qeft_decode_linear
+        _lib.check(entry(
             x.data_ptr(), op.qweight.data_ptr(), szp.data_ptr(), ow.data_ptr() if r else None,
             op.bias.data_ptr() if op.bias is not None else None, y.data_ptr(), n, k, g, r, mode,
             residual.data_ptr() if residual is not None else None,
