@@ -74,12 +74,13 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     if (smem > 160 * 1024 || nblk >= 65536) return hipErrorInvalidValue;       // (nblk, sets_r share dwords with rs_cap, sets_q)
     // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
     static const int f_nw = env_int("QEFT_GEMV_NW"), f_d = env_int("QEFT_GEMV_DEPTH");     // lab overrides
-    // measured (tools/gemv_v3_lab.hip, profiles/r02_gemv_v3_lab.txt): 16 waves + depth 2 win where a CU holds one block and a
-    // wave still has several steps (q|k|v 8.3 vs 9.0 us, down_proj 8.0 vs 8.9); o_proj (2 steps per wave at 16) keeps 8
-    // waves; two blocks per CU (gate|up) run best at 8 waves, depth 2 (12.9 vs 14.3 at depth 4, 16.6 at 6: registers)
+    // measured (tools/gemv_v3_lab.hip, profiles/r02_gemv_v3_lab.txt, and A/B runs of the whole decode step): 16 waves where a
+    // CU holds one block and a wave still has several steps (q|k|v 8.3 vs 9.0 us, down_proj 8.0 vs 8.9); o_proj (2 steps
+    // per wave at 16) keeps 8 waves; two blocks per CU (gate|up) run best at 8 waves.  Ring depth 2 everywhere: gate|up 12.9
+    // vs 14.3 us at depth 4 (16.6 at 6: registers), o_proj 4.72 vs 5.08 with the preloaded prologue, the 3-bit stream likewise
     const int steps16 = ceil_div(a.g.nfull, 16) * a.rs_cap;
     const int nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 && steps16 >= 4 ? 16 : 8);
-    const int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : (nw == 16 || nblk > 256 ? 2 : 4);
+    const int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : 2;
     const bool w3 = a.bits == 3;
     g_last_variant = mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
     return w3 ? launch_b<3>(a, mode, nblk, smem, nw, depth, st) : launch_b<4>(a, mode, nblk, smem, nw, depth, st);
