@@ -252,8 +252,14 @@ def gemm_records(dev, m=2048, layers=4, reps=25):
         fwd_recs.append({"shape": f"{n}x{k}", "us": round(t_f, 1), "TFLOPs": round(flops / t_f / 1e6, 1),
                          "frac_of_peak": round(flops / t_f / 1e6 / MFMA_PEAK_TFLOPS, 4), "variant": variants["fwd"],
                          "hipblaslt_dense_fp16_us": round(t_d, 1), "hipblaslt_dense_fp16_TFLOPs": round(flops / t_d / 1e6, 1)})
+        # BASELINE config 5 names the 3-bit pack: a w3 layer's GEMM / backward run the same kernels on its 3 -> 4-bit expansion
+        # (QuantLinear(bits=3) keeps one expanded copy per layer while training), so its step adds this pass once
+        q3 = torch.randint(-2 ** 31, 2 ** 31 - 1, (n // 16, (k - r) // 128 * 192), dtype=torch.int32, device=dev)
+        q4 = torch.empty(n // 4, k, dtype=torch.int16, device=dev)
+        t_e = _event_time_us(lambda: qeft_cuda.expand_3bit(q3, n, k, r, out=q4), reps, dev)
+        del q3, q4
         ft_recs.append({"shape": f"{n}x{k}", "forward_us": round(t_f, 1), "dx_us": round(t_x, 1), "dow_us": round(t_w, 1),
-                        "step_us": round(t_f + t_x + t_w, 1),
+                        "step_us": round(t_f + t_x + t_w, 1), "w3_expand_us": round(t_e, 1),
                         "dx_TFLOPs": round(flops / t_x / 1e6, 1), "dx_frac_of_peak": round(flops / t_x / 1e6 / MFMA_PEAK_TFLOPS, 4),
                         "step_TFLOPs": round((2 * flops + 2.0 * m * n * r) / (t_f + t_x + t_w) / 1e6, 1),
                         "variants": dict(variants)})
@@ -441,7 +447,7 @@ def main():
                                       "note": "2048-token prompt through every packed linear (GEMM path), torch fused SDPA attention"}
                 extras["prefill_2048"] = pre
                 extras["finetune_step"] = {"M": 2048, "per_shape": ft_recs,
-                                           "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44)"}
+                                           "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44); w3_expand_us: the 3 -> 4-bit expansion a 3-bit layer adds (once per step: the expanded copy is kept while training)"}
             except Exception as e:
                 print(f"[bench] GEMM sub-records failed: {type(e).__name__}: {e}", file=sys.stderr)
 

@@ -227,6 +227,8 @@ int qeft_token_begin_norm(const void* embed, const void* tok, const void* rope_t
                           const void* gamma, void* h_norm, float* ssq_out, int hidden, int vocab, int max_seq,
                           qeft_stream_t stream);
 int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hidden, float eps, qeft_stream_t stream); /* qeft_rmsnorm on an fp32 input */
+/* qeft_rope_rows (prefill helper): NeoX rotary of x [t][n_heads][128] fp16 in place, cos_tab / sin_tab fp32 [t][64]. */
+int qeft_rope_rows(void* x, const void* cos_tab, const void* sin_tab, int t, int n_heads, qeft_stream_t stream);
 /* qeft_lm_head_f16 (decode harness, token tail): logits[vocab] (fp16) = weight[vocab][hidden] (fp16, the unquantized lm_head)
  * . fp16(rmsnorm(h32) * gamma) -- the final norm of qeft_rmsnorm_f32 and the head GEMV in one launch, fp32 accumulation.
  * hidden in {512, 1024, 2048, 4096, 5120, 8192}. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "qeft_token_begin_norm": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_rmsnorm_f32": [_p, _p, _p, _i, _i, ctypes.c_float, _p],
     "qeft_lm_head_f16": [_p, _p, _p, _p, _i, _i, ctypes.c_float, _p],
+    "qeft_rope_rows": [_p, _p, _p, _i, _i, _p],
     "qeft_residual_norm": [_p, _p, _p, _p, _p, _p, _i, _p],
     "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -18,6 +18,7 @@ int token_begin_norm_blocks(int hidden);
 hipError_t residual_norm_launch(const void* h, const void* add, const void* gamma, void* h_out, void* hnorm, float* ssq_out,
                                 int hidden, hipStream_t st);
 hipError_t rmsnorm_f32_launch(const void* x, const void* gamma, void* y, int m, int H, float eps, hipStream_t st);
+hipError_t rope_rows_launch(void* x, const void* cs, const void* sn, int T, int H, hipStream_t st);
 hipError_t lm_head_f16_launch(const void* h32, const void* gamma, const void* W, void* logits, int H, int vocab, float eps,
                               hipStream_t st);
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
@@ -418,6 +419,12 @@ int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hid
     if (!x32 || !gamma || !y) return QEFT_ERR_NULL;
     if (!aligned16(x32) || !aligned16(y) || !aligned16(gamma)) return QEFT_ERR_ALIGN;
     return finish(qeft::rmsnorm_f32_launch(x32, gamma, y, m, hidden, eps, (hipStream_t)stream));
+}
+
+int qeft_rope_rows(void* x, const void* cos_tab, const void* sin_tab, int t, int n_heads, qeft_stream_t stream) {
+    if (t < 1 || n_heads < 1) return QEFT_ERR_SHAPE;
+    if (!x || !cos_tab || !sin_tab) return QEFT_ERR_NULL;
+    return finish(qeft::rope_rows_launch(x, cos_tab, sin_tab, t, n_heads, (hipStream_t)stream));
 }
 
 int qeft_lm_head_f16(const void* h32, const void* gamma, const void* weight, void* logits, int hidden, int vocab, float eps,

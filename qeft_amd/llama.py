@@ -201,6 +201,15 @@ def _rmsnorm(x, gamma, eps):
     return y
 
 
+def _add_rmsnorm(x, add, gamma, eps):
+    """h = x + add (fp16, rounded once like the torch add), y = rmsnorm(h) * gamma: one launch (qeft_rmsnorm's fused form).
+    Returns (h, y)."""
+    h, y = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.lib().qeft_rmsnorm(x.data_ptr(), add.data_ptr(), gamma.data_ptr(), h.data_ptr(), y.data_ptr(), x.shape[0],
+                                       x.shape[1], eps, torch.cuda.current_stream(x.device).cuda_stream))
+    return h, y
+
+
 def _silu_mul(gate, up):
     out = torch.empty_like(gate)
     _lib.check(_lib.lib().qeft_silu_mul(gate.data_ptr(), up.data_ptr(), out.data_ptr(), gate.numel(),
@@ -221,13 +230,24 @@ def prefill(model: "QuantLlama", tokens, engine=None):
     h = model.model.embed_tokens.weight[tokens]                       # [T, hidden] fp16
     cos, sin = model.rope_cos[:T, None, :], model.rope_sin[:T, None, :]
 
-    def rope(x):                                                      # [T, H, 128] fp16 -> rotated fp16 (fp32 math)
+    cos_t, sin_t = model.rope_cos[:T].contiguous(), model.rope_sin[:T].contiguous()
+    lib = _lib.lib()
+
+    def rope(x):                                                      # [T, H, 128] fp16 -> rotated fp16 (fp32 math), in place
+        if x.is_cuda and x.is_contiguous():
+            _lib.check(lib.qeft_rope_rows(x.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), T, x.shape[1],
+                                          torch.cuda.current_stream(x.device).cuda_stream))
+            return x
         a, b = x[..., :64].float(), x[..., 64:].float()
         return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1).half()
 
+    delta = None                                                      # the previous layer's down_proj output, added by the next norm
     for li, L in enumerate(model.model.layers):
         at, mlp = L.self_attn, L.mlp
-        x = _rmsnorm(h, L.input_layernorm, s.rms_eps)
+        if delta is None:
+            x = _rmsnorm(h, L.input_layernorm, s.rms_eps)
+        else:
+            h, x = _add_rmsnorm(h, delta, L.input_layernorm, s.rms_eps)
         q = rope(at.q_proj(x).view(T, s.n_heads, 128))
         k = rope(at.k_proj(x).view(T, s.n_kv_heads, 128))
         v = at.v_proj(x).view(T, s.n_kv_heads, 128)
@@ -241,12 +261,12 @@ def prefill(model: "QuantLlama", tokens, engine=None):
         a = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], kk.transpose(0, 1)[None],
                                                              vv.transpose(0, 1)[None], is_causal=True)[0]    # [H, T, 128]
         a = a.transpose(0, 1).reshape(T, s.hidden).contiguous()
-        h = h + at.o_proj(a)                                          # o_proj gathers its own column order
-        x = _rmsnorm(h, L.post_attention_layernorm, s.rms_eps)
-        h = h + mlp.down_proj(_silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
+        h, x = _add_rmsnorm(h, at.o_proj(a), L.post_attention_layernorm, s.rms_eps)     # o_proj gathers its own column order
+        delta = mlp.down_proj(_silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
     if engine is not None:
         engine.set_position(T)
-    return torch.matmul(_rmsnorm(h, model.model.norm, s.rms_eps), model.lm_head.weight.t())
+    _, hn = _add_rmsnorm(h, delta, model.model.norm, s.rms_eps)
+    return torch.matmul(hn, model.lm_head.weight.t())
 
 
 def _ptr_array(tensors):
