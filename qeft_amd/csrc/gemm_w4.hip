@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
     const int tslot = wave * 4 + ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
     const uint32_t w_rd = (uint32_t)(D3_WOFF + (32 * h + tq) * 256 + ((tslot ^ (tq << 2) ^ tq) << 4) + (lane & 1) * 8);
     auto tr_read = [&](uint32_t off) -> u32x2 {
-        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lds0 + off)));
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(uintptr_t)(lds0 + off)));
     };
     auto fetch_w = [&](int buf, int j, u32x4& dst) {
         const u32x2 lo = tr_read(w_rd + buf * D3_W + (8 * j) * 256), hi = tr_read(w_rd + buf * D3_W + (8 * j + 4) * 256);
