@@ -117,3 +117,29 @@ def test_shim_exports_the_reference_module_surface():
     x = torch.zeros(1, 2, 128, dtype=torch.float16)
     with pytest.raises(RuntimeError):        # CPU tensors raise: no host fallback for the FT entries either
         qeft_cuda.layernorm_forward_cuda(x, torch.ones(128, dtype=torch.float16), torch.empty_like(x), 1e-5)
+
+
+def test_round2_entries_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call: NULL operands, misaligned pointers and shapes the kernels do not
+    take come back as error codes (no launch, no GPU needed)."""
+    from qeft_amd import _lib
+    lib = _lib.lib()
+    ok_ptr = 1 << 20            # a non-NULL, 16-byte aligned address: validation must fail before anything dereferences it
+    # decode GEMVs: K not a multiple of 128 / n not a multiple of 16 / an outlier width the kernel does not take
+    for entry in (lib.qeft_decode_linear, lib.qeft_decode_linear_w3):
+        assert entry(ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4000, 128, 128, 0, None, None, 0, 0.0, None, None, None, None) != 0
+        assert entry(ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4090, 4096, 128, 128, 0, None, None, 0, 0.0, None, None, None, None) != 0
+        assert entry(ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4096, 128, 64, 0, None, None, 0, 0.0, None, None, None, None) != 0
+        assert entry(None, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4096, 128, 128, 0, None, None, 0, 0.0, None, None, None, None) != 0
+        assert entry(ok_ptr + 2, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4096, 128, 128, 0, None, None, 0, 0.0, None, None, None, None) != 0
+        # gamma_out without a residual, and more partial sums than a consumer accepts
+        assert entry(ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4096, 128, 128, 0, None, None, 0, 0.0, ok_ptr, ok_ptr, ok_ptr, None) != 0
+        assert entry(ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4096, 128, 128, 0, None, ok_ptr, 513, 1e-5, None, None, None, None) != 0
+    assert lib.qeft_decode_linear_hnorm(ok_ptr, None, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4096, 128, 128, 0, 1e-5, None) != 0
+    assert lib.qeft_decode_linear_hnorm(ok_ptr, ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4100, 128, 128, 0, 1e-5, None) != 0
+    assert lib.qeft_lm_head_f16(ok_ptr, ok_ptr, ok_ptr, ok_ptr, 4000, 32000, 1e-5, None) != 0      # hidden not a multiple of 512
+    assert lib.qeft_lm_head_f16(ok_ptr, ok_ptr, None, ok_ptr, 4096, 32000, 1e-5, None) != 0
+    assert lib.qeft_rope_rows(None, ok_ptr, ok_ptr, 4, 2, None) != 0
+    assert lib.qeft_rope_rows(ok_ptr, ok_ptr, ok_ptr, 0, 2, None) != 0
+    assert lib.qeft_decode_linear_blocks(4096) == 256 and lib.qeft_decode_linear_blocks(22016) == 459
+    assert lib.qeft_decode_linear_blocks(5120) == 160          # between 256 and 512 row sets: two per block
