@@ -6,7 +6,8 @@ never consumed, so no numeric check sees them; they fault only when the operand 
 The cases below run in a child process with PYTORCH_NO_CUDA_MEMORY_CACHING=1 (every tensor its own hipMalloc, so an
 operand ends at the end of its allocation instead of somewhere inside a 2 MiB pool segment), on the shapes where the
 clamps bite: one 16-row set, K below / at / just above one step and one staging pass, last blocks with fewer row sets
-than rs_cap, batch slices, ragged GEMM tiles.  Every result is also checked against the oracle, so a clamp that
+than rs_cap, batch slices, ragged GEMM tiles, and (round 2) the 256-row GEMM / dX tiles with their loader waves, the
+round-2 decode launches on their smallest shapes, the fused token tail.  Every result is also checked against the oracle, so a clamp that
 "fixes" a fault by reading the wrong bytes fails too.  Runs last (file name) and once."""
 import os
 import subprocess
@@ -72,6 +73,64 @@ gemv(64, 11008, 128, 128, 7)
 for (n, k, r, g, m) in [(136, 192, 0, 64, 129), (8, 64, 0, 64, 1), (264, 256, 128, 128, 17), (128, 1024, 128, 128, 130),
                         (520, 2048, 64, 128, 257), (256, 4096, 128, 128, 200)]:
     gemm(n, k, r, g, m)
+# ---- round 2: the 256-row GEMM / dX tiles (loader waves: DMA pieces, the register ring of packed weights, the outlier k-tile's
+# direct DMA), ragged M / N, every remainder class of the dX loader's ring
+import types
+from qeft_amd import fuse
+for (n, k, r, g, m) in [(5896, 512, 64, 64, 1100), (5888, 384, 0, 128, 1025)]:
+    b = O.make_layer(n, k, r, g, seed=n + m)
+    t = layer_to_torch(b, DEV)
+    x = O.make_activation(m, k, r, seed=m)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    assert _lib.last_variant() == "gemm_v3_256x128", _lib.last_variant()
+    torch.cuda.synchronize()
+    ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g)
+    assert rel_err(y.cpu().numpy(), ref.astype(np.float64)) < 1e-3, ("gemm v3", n, k, r, g, m)
+for (n, k, r, g, m) in [(256, 6144, 128, 128, 1100), (320, 6144, 0, 128, 1025), (448, 6144, 128, 128, 1100)]:
+    b = O.make_layer(n, k, r, g, seed=n + m)
+    t = layer_to_torch(b, DEV)
+    dy = (np.random.default_rng(n).standard_normal((m, n)) * 0.1).astype(np.float16)
+    dx = qeft_cuda.gemm_4bit_dx(torch.from_numpy(dy).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    assert _lib.last_variant() == "dx256", _lib.last_variant()
+    torch.cuda.synchronize()
+    w = O.dequant_dense(b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, g)
+    assert rel_err(dx.cpu().numpy(), dy.astype(np.float64) @ w.astype(np.float64)) < 2e-3, ("dx256", n, k, r, g, m)
+# ---- round 2 decode launches on their smallest shapes: plain / pair / consumer-side norm / 3-bit stream, fused token tail, rotary rows
+def operand(n, k, r, bits=4, seed=0):
+    b = O.make_layer(n, k, r, 128, seed=seed, bits=bits)
+    t = layer_to_torch(b, DEV)
+    l = types.SimpleNamespace(qweight=t["qweight"], scales=t["scales"], scaled_zeros=t["scaled_zeros"], oweight=t.get("oweight"), bias=None,
+                              outfeatures=n, infeatures=k, group_size=128, outlierfeatures=r, bits=bits)
+    l.sz_packed = qeft_cuda.pack_scales(l.scales, l.scaled_zeros, n, k, 128)
+    return l, b
+for (n, k, r) in [(16, 128, 0), (16, 256, 128), (48, 640, 128), (16 * 257, 256, 128)]:
+    for bits in (4, 3):
+        l, b = operand(n, k, r, bits, seed=n + k + bits)
+        x = O.make_activation(1, k, r, seed=3)
+        y = qeft_cuda.decode_linear(torch.from_numpy(x[0]).to(DEV), l)
+        torch.cuda.synchronize()
+        ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, 128)
+        assert rel_err(y.cpu().numpy()[None], ref.astype(np.float64)) < 1e-3, ("v3", n, k, r, bits)
+    lg, bg = operand(n, k, r, 4, seed=n); lu, bu = operand(n, k, r, 4, seed=n + 1)
+    h = (np.random.default_rng(n).standard_normal(k) * 2).astype(np.float32)
+    gam = np.ones(k, dtype=np.float16)
+    act = qeft_cuda.decode_linear_hnorm(torch.from_numpy(h).to(DEV), torch.from_numpy(gam).to(DEV), fuse.pair_interleave(lg, lu), mode=qeft_cuda.V3_PAIR)
+    torch.cuda.synchronize()
+    xn = h.astype(np.float64) / np.sqrt((h.astype(np.float64) ** 2).mean() + 1e-5)
+    wg = O.dequant_dense(bg["qweight"], bg["scales"], bg["scaled_zeros"], bg.get("oweight") if r else None, 128).astype(np.float64) @ xn
+    wu = O.dequant_dense(bu["qweight"], bu["scales"], bu["scaled_zeros"], bu.get("oweight") if r else None, 128).astype(np.float64) @ xn
+    assert rel_err(act.cpu().numpy(), wg / (1 + np.exp(-wg)) * wu) < 4e-3, ("hnorm pair", n, k, r)
+lib = _lib.lib()
+st = torch.cuda.current_stream().cuda_stream
+hh = torch.randn(512, device=DEV); gg = torch.ones(512, device=DEV).half(); ww = (torch.randn(7, 512, device=DEV) * 0.05).half()
+lo = torch.empty(7, dtype=torch.float16, device=DEV)
+_lib.check(lib.qeft_lm_head_f16(hh.data_ptr(), gg.data_ptr(), ww.data_ptr(), lo.data_ptr(), 512, 7, 1e-5, st))
+rr = torch.randn(3, 1, 128, device=DEV).half(); cc = torch.randn(3, 64, device=DEV); ss = torch.randn(3, 64, device=DEV)
+want = torch.cat([rr[..., :64].float() * cc[:, None] - rr[..., 64:].float() * ss[:, None], rr[..., 64:].float() * cc[:, None] + rr[..., :64].float() * ss[:, None]], -1).half()
+_lib.check(lib.qeft_rope_rows(rr.data_ptr(), cc.data_ptr(), ss.data_ptr(), 3, 1, st))
+torch.cuda.synchronize()
+hn = (hh * torch.rsqrt((hh ** 2).mean() + 1e-5)).half()
+assert (lo.float() - hn.float() @ ww.float().t()).abs().max().item() < 2e-2 and torch.equal(rr, want)
 print("GUARD-OK")
 '''
 
