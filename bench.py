@@ -463,8 +463,11 @@ def main():
                                    f"greedy, KV context {ctx0}..{ctx0 + args.steps} tokens ({CONTEXT}-token context + "
                                    f"{args.warmup} warm-up tokens before the timed region)",
                        "layers": shape.n_layers, "hipgraph": graph_ok,
-                       "parallelism": (f"tp{world}: q/k/v/gate/up row-sharded, o/down column-sharded + one all-reduce each "
-                                       f"(2 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})")
+                       "parallelism": ((f"tp{world}: q/k/v/gate/up row-sharded, o/down column-sharded + one all-reduce each "
+                                        f"(2 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})")
+                                       if getattr(eng, "tp3", False) else
+                                       (f"tp{world}: every linear row-sharded, one all-gather each "
+                                        f"(4 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})"))
                        if group is not None else "single GPU",
                        "build_s": round(t_build, 1), "last_token": last_tok},
         }
