@@ -44,7 +44,8 @@ int qeft_abi_version(void);
 const char* qeft_error_string(int code);
 int qeft_last_hip_error(void);
 /* Name of the kernel variant the calling thread's most recent compute entry point launched, e.g. "gemv_mfma",
- * "gemm_v2_128x256", "gemm_v2_128x128+splitk", "gemv_smallm", "dx128", "dx64+split", "grad_oweight_mfma".  Static storage;
+ * "gemm_v2_128x256", "gemm_v2_128x128+splitk", "gemv_smallm", "dx128", "dx64+split", "grad_oweight_mfma",
+ * "grad_oweight_mfma_n64".  Static storage;
  * diagnostic only (the parity tests assert it so that every routing tier keeps its coverage). */
 const char* qeft_last_variant(void);
 

@@ -1570,124 +1570,178 @@ __global__ __launch_bounds__(256) void grad_oweight_kernel(const f16* __restrict
 }
 
 // MFMA version.  d_oweight = dy^T . x_o contracts over m, the ROW index of both operands, so both MFMA fragments are
-// columns of row-major tiles: [128 m][32 n] of dy and [128 m][64 j] of x_o are staged as they lie in HBM (16-byte
-// copies) and read back with the transposing LDS read (as the weight tile of gemm_w4_dx_kernel).  Block = 32 (n) x 64
-// (j) outputs over ALL m (no cross-block reduction: deterministic); its 4 waves take alternate 16-m steps and are
-// summed through LDS in wave order at the end.  The first version (fp32 FMAs on an LDS tile) took longer than the dX
-// GEMM although it has 3 % of its flops.
-constexpr int GO_BN = 32, GO_BJ = 64, GO_BM = 128;
-constexpr int GO_PDY = GO_BN * 2 + 16;   // bytes per m row of the dy tile
-constexpr int GO_PX = GO_BJ * 2 + 16;    // bytes per m row of the x_o tile
+// columns of row-major tiles: rows of dy and x_o go to LDS as they lie in HBM (16-byte copies) and come back through the
+// transposing LDS read (as the weight tile of gemm_w4_dx_kernel).  Block = BN (n) x 64 (j) outputs over ALL m (no
+// cross-block reduction: deterministic).  A wave owns 32 of every 128 rows end to end: its loads (D slabs in flight in
+// registers), a PRIVATE 7-9 KB of LDS it writes and reads back transposed (LDS operations of one wave execute in order,
+// so one buffer is enough and no barrier is involved), its MFMAs; the fragments of slab i+1 are fetched before the MFMAs
+// of slab i.  The four waves meet once, in the final sum (wave order).
+// History: fp32 FMAs on an LDS tile took longer than the dX GEMM for 3 % of its flops; block-wide 128-row stages with
+// two barriers each (round 1) were not memory-bound either -- with every load an L2 hit they still took 0.4 us per stage,
+// the serial chain wait / store / barrier / read / MFMA / barrier of four waves in lock step.  What bounds this form is
+// the bytes a CU takes in (~55 GB/s per CU here, as in the GEMM's k loop): 2 (BN + 64) bytes per m row and block, so
+// BN = 64 for wide layers, where 32-column blocks would put three blocks on a CU.
+constexpr int GO_BJ = 64;
+constexpr int GO_PX = GO_BJ * 2 + 16;    // bytes per m row of the x_o slab
 
-__global__ __launch_bounds__(256) void grad_oweight_mfma_kernel(const f16* __restrict__ dy, const f16* __restrict__ x,
+template <int BN, int D>
+__global__ __launch_bounds__(256) void grad_oweight_wave_kernel(const f16* __restrict__ dy, const f16* __restrict__ x,
                                                                 float* __restrict__ dow, int M, int N, int K, int R) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_dy[GO_BM * GO_PDY];
-    __shared__ __attribute__((aligned(16))) uint8_t lds_x[GO_BM * GO_PX];
-    __shared__ float red[4][2][16][64];
+    constexpr int PDY = BN * 2 + 16;     // bytes per m row of the dy slab
+    constexpr int NT = BN / 32;          // 32-column MFMA tiles of dy
+    constexpr int DPR = BN / 8;          // 16-byte pieces per dy row
+    constexpr int ND = 32 * DPR / 64;    // dy loads per lane and slab
+    constexpr int WB = 32 * (PDY + GO_PX);
+    constexpr int GO_LDS = 4 * WB > 32768 ? 4 * WB : 32768;
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[GO_LDS];
+    float(*const red)[2][16][64] = (float(*)[2][16][64])lds_all;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * GO_BN, j0 = blockIdx.y * GO_BJ, kq = K - R;
+    uint8_t* const wdy = lds_all + wave * WB;
+    uint8_t* const wx = wdy + 32 * PDY;
+    const int n0 = blockIdx.x * BN, j0 = blockIdx.y * GO_BJ, kq = K - R;
 
-    f32x16 acc[2];
+    f32x16 acc[NT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jt][e] = 0.f;
 
     struct Stage {
-        u32x4 d[2];    // dy: items tid, tid + 256 -> (row = item >> 2, 16-byte piece = item & 3)
-        u32x4 xv[4];   // x_o: items tid + 256 i  -> (row = item >> 3, piece = item & 7)
+        u32x4 d[ND];   // dy: items lane + 64 i -> (row = item / DPR, 16-byte piece = item % DPR)
+        u32x4 xv[4];   // x_o: items lane + 64 i -> (row = item >> 3, piece = item & 7)
     };
-    // loads are unconditional (clamped addresses): a load in a branch makes hipcc drain vmcnt(0) on the spot, which would
-    // empty the ring of stages below; what lies outside [M) x [N) / [R) is zeroed when the stage is written to LDS
-    auto gload = [&](int m0, Stage& st) {
+    struct Frag {
+        u32x2 a[2][NT][2], b[2][2][2];     // [16-row step][tile][rows 0-3 / 4-7 of the lane's 8]
+    };
+    // slab s of this wave = rows 128 s + 32 wave ..; loads are unconditional with clamped addresses (a load in a branch
+    // makes hipcc drain vmcnt(0)); what lies outside [M) x [N) / [R) is zeroed on its way into LDS
+    auto gload = [&](int s, Stage& st) {
+        const int m0 = s * 128 + wave * 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int item = tid + 256 * i, m = min(m0 + (item >> 2), M - 1), n = min(n0 + (item & 3) * 8, N - 8);
+        for (int i = 0; i < ND; ++i) {
+            const int item = lane + 64 * i, m = min(m0 + item / DPR, M - 1), n = min(n0 + (item % DPR) * 8, N - 8);
             st.d[i] = *(const u32x4*)(dy + (size_t)m * N + n);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int item = tid + 256 * i, m = min(m0 + (item >> 3), M - 1), j = min(j0 + (item & 7) * 8, R - 8);
+            const int item = lane + 64 * i, m = min(m0 + (item >> 3), M - 1), j = min(j0 + (item & 7) * 8, R - 8);
             st.xv[i] = *(const u32x4*)(x + (size_t)m * K + kq + j);
         }
     };
-    auto lstore = [&](const Stage& st, int m0) {
+    auto lstore = [&](const Stage& st, int s) {
+        const int m0 = s * 128 + wave * 32;
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int item = tid + 256 * i;
-            const bool ok = m0 + (item >> 2) < M && n0 + (item & 3) * 8 < N;
-            *(u32x4*)(lds_dy + (item >> 2) * GO_PDY + (item & 3) * 16) = ok ? st.d[i] : z;
+        for (int i = 0; i < ND; ++i) {
+            const int item = lane + 64 * i;
+            const bool ok = m0 + item / DPR < M && n0 + (item % DPR) * 8 < N;
+            *(u32x4*)(wdy + (item / DPR) * PDY + (item % DPR) * 16) = ok ? st.d[i] : z;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int item = tid + 256 * i;
+            const int item = lane + 64 * i;
             const bool ok = m0 + (item >> 3) < M && j0 + (item & 7) * 8 < R;
-            *(u32x4*)(lds_x + (item >> 3) * GO_PX + (item & 7) * 16) = ok ? st.xv[i] : z;
+            *(u32x4*)(wx + (item >> 3) * GO_PX + (item & 7) * 16) = ok ? st.xv[i] : z;
         }
     };
     // transposed-read addresses (16-m step 0): lane 4q+p of a 16-lane group addresses row q, columns 4p.. of its block;
     // group g = lane >> 4 -> columns (g & 1)*16 .., contraction rows 8*(g >> 1) ..
     const uint32_t rowsel = (uint32_t)(8 * (lane >> 5) + ((lane & 15) >> 2));
     const uint32_t colsel = (uint32_t)(((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
-    const uint32_t a_tr = (uint32_t)(uintptr_t)lds_dy + rowsel * GO_PDY + colsel;
-    const uint32_t b_tr = (uint32_t)(uintptr_t)lds_x + rowsel * GO_PX + colsel;
-
-    // Three stages in flight (registers): with one, a block spent ~0.9 us per 128-row stage waiting for its own loads
-    // (15 us for M = 2048; the launch is 3 % of the step's flops).  Rows past M load as zeros, so the ring needs no tail logic.
-    auto body = [&](Stage& st, int m0, int m_refill) {
-        lstore(st, m0);
-        __syncthreads();
-        gload(m_refill, st);
+    auto tr_read = [&](const uint8_t* p) -> u32x2 {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(uintptr_t)p));
+    };
+    const uint8_t* const a_tr = wdy + rowsel * PDY + colsel;
+    const uint8_t* const b_tr = wx + rowsel * GO_PX + colsel;
+    auto fetch = [&](Frag& f) {
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            const uint32_t row = (uint32_t)(wave * 2 + ss) * 16;
-            const u32x2 a0 = lds_read_tr8(a_tr + row * GO_PDY), a1 = lds_read_tr8(a_tr + (row + 4) * GO_PDY);
-            u32x2 b[2][2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f.a[ss][nt][0] = tr_read(a_tr + (ss * 16) * PDY + nt * 64);
+                f.a[ss][nt][1] = tr_read(a_tr + (ss * 16 + 4) * PDY + nt * 64);
+            }
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                b[jt][0] = lds_read_tr8(b_tr + row * GO_PX + jt * 64);
-                b[jt][1] = lds_read_tr8(b_tr + (row + 4) * GO_PX + jt * 64);
+                f.b[ss][jt][0] = tr_read(b_tr + (ss * 16) * GO_PX + jt * 64);
+                f.b[ss][jt][1] = tr_read(b_tr + (ss * 16 + 4) * GO_PX + jt * 64);
             }
-            lds_wait();
-            const h8 af = __builtin_bit_cast(h8, u32x4{a0[0], a0[1], a1[0], a1[1]});
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                    af, __builtin_bit_cast(h8, u32x4{b[jt][0][0], b[jt][0][1], b[jt][1][0], b[jt][1][1]}), acc[jt], 0, 0, 0);
         }
-        __syncthreads();
     };
-    Stage s0, s1, s2;
-    gload(0, s0);
-    gload(GO_BM, s1);
-    gload(2 * GO_BM, s2);
-    for (int m0 = 0; m0 < M; m0 += 3 * GO_BM) {
-        body(s0, m0, m0 + 3 * GO_BM);
-        body(s1, m0 + GO_BM, m0 + 4 * GO_BM);          // past M: a stage of zeros
-        body(s2, m0 + 2 * GO_BM, m0 + 5 * GO_BM);
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+                    acc[nt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(h8, u32x4{f.a[ss][nt][0][0], f.a[ss][nt][0][1], f.a[ss][nt][1][0], f.a[ss][nt][1][1]}),
+                        __builtin_bit_cast(h8, u32x4{f.b[ss][jt][0][0], f.b[ss][jt][0][1], f.b[ss][jt][1][0], f.b[ss][jt][1][1]}),
+                        acc[nt][jt], 0, 0, 0);
+    };
+
+    const int slabs = (M + 127) >> 7;
+    Stage st[D];
+    Frag cur, nxt;
+#pragma unroll
+    for (int i = 0; i < D; ++i) gload(i, st[i]);
+    lstore(st[0], 0);
+    gload(D, st[0]);
+    fetch(cur);
+    // body for slab s (in stage st[s % D]): its rows go to LDS behind the reads of slab s-1 that are already issued, its
+    // stage is refilled, its fragments are fetched, and the MFMAs of slab s-1 run while they arrive.  Slabs past the
+    // last are zeros.
+    for (int s0 = 1; s0 <= slabs; s0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            Stage& sg = st[(i + 1) % D];
+            lstore(sg, s0 + i);
+            gload(s0 + i + D, sg);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
     }
+    __syncthreads();                                   // every wave is done with its slab buffer: `red` lies over them
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int nt = 0; nt < NT; ++nt) {                  // 32 columns of dy at a time through the 32 KB
+        if (nt) __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[wave][jt][e][lane] = acc[jt][e];
-    __syncthreads();
-    for (int idx = tid; idx < 2 * 16 * 64; idx += 256) {
-        const int jt = idx >> 10, e = (idx >> 6) & 15, l = idx & 63;
-        const float v = ((red[0][jt][e][l] + red[1][jt][e][l]) + red[2][jt][e][l]) + red[3][jt][e][l];
-        const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), j = j0 + jt * 32 + (l & 31);
-        if (n < N && j < R) dow[(size_t)n * R + j] = v;
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave][jt][e][lane] = acc[nt][jt][e];
+        __syncthreads();
+        for (int idx = tid; idx < 2 * 16 * 64; idx += 256) {
+            const int jt = idx >> 10, e = (idx >> 6) & 15, l = idx & 63;
+            const float v = ((red[0][jt][e][l] + red[1][jt][e][l]) + red[2][jt][e][l]) + red[3][jt][e][l];
+            const int n = n0 + nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5), j = j0 + jt * 32 + (l & 31);
+            if (n < N && j < R) dow[(size_t)n * R + j] = v;
+        }
     }
 }
 
 hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, int N, int K, int n_out,
                                hipStream_t st) {
     if (N % 8 == 0 && n_out % 8 == 0 && K % 8 == 0) {   // 16-byte row pieces
-        dim3 grid2((N + GO_BN - 1) / GO_BN, (n_out + GO_BJ - 1) / GO_BJ);
-        hipLaunchKernelGGL(grad_oweight_mfma_kernel, grid2, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (float*)dow, M,
-                           N, K, n_out);
-        g_last_variant = "grad_oweight_mfma";
+        static const int force_bn = [] { const char* e = getenv("QEFT_DOW_BN"); return e ? atoi(e) : 0; }();
+        const int jb = (n_out + GO_BJ - 1) / GO_BJ;
+        const bool wide = force_bn ? force_bn == 64 : (N + 31) / 32 * jb > 512;
+        const dim3 grid2((N + (wide ? 63 : 31)) / (wide ? 64 : 32), jb);
+        if (wide)
+            hipLaunchKernelGGL((grad_oweight_wave_kernel<64, 2>), grid2, dim3(256), 0, st, (const f16*)dy, (const f16*)x,
+                               (float*)dow, M, N, K, n_out);
+        else
+            hipLaunchKernelGGL((grad_oweight_wave_kernel<32, 2>), grid2, dim3(256), 0, st, (const f16*)dy, (const f16*)x,
+                               (float*)dow, M, N, K, n_out);
+        g_last_variant = wide ? "grad_oweight_mfma_n64" : "grad_oweight_mfma";
         return hipGetLastError();
     }
     g_last_variant = "grad_oweight_fma";
