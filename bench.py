@@ -374,6 +374,18 @@ def main():
                 "kernel": f"{eng.gemv_kernel_name()} (4 launches per layer)",
                 "bytes_per_launch": int(bytes_per_launch), "us_per_launch": round(us_per_launch, 3),
                 "frac_of_copy_ceiling_6300": round(achieved / 6300.0, 4)}
+        if world == 1:
+            # a stream ceiling measured on THIS box in the same run -- a 1 GiB device-to-device copy (read +
+            # write counted) and a 1 GiB read (sum); the GEMV fraction against the faster of the two beside the nominal one
+            src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty_like(src)
+            t_copy = _event_time_us(lambda: dst.copy_(src), 10, dev)
+            t_read = _event_time_us(lambda: src.sum(), 10, dev)
+            copy_gbps, read_gbps = 2 * src.numel() * 4 / t_copy / 1e3, src.numel() * 4 / t_read / 1e3
+            roof["stream_ceiling_measured"] = {"copy_GB/s": round(copy_gbps, 1), "read_GB/s": round(read_gbps, 1),
+                                               "frac": round(achieved / max(copy_gbps, read_gbps), 4),
+                                               "note": "1 GiB torch copy_ (read + write bytes) and 1 GiB torch sum on this box"}
+            del src, dst
         if traffic is not None:
             roof["traffic"] = traffic["bytes_per_launch"]
             roof["traffic_note"] = (f"FETCH_SIZE x 1024 x 2 (gfx950 correction), mean over {traffic['launches_sampled']} "
