@@ -99,6 +99,24 @@ def test_backward_dx_and_doweight(m, n, k, r, g):
         assert rel_err(dow.cpu().numpy(), dow_ref) < REL_TOL
 
 
+@pytest.mark.parametrize("m,n,k,r", [(130, 8456, 256, 72), (1, 8200, 128, 8), (300, 16384, 192, 128), (257, 264, 320, 200)])
+def test_doweight_block_widths_ragged(m, n, k, r):
+    """d(oweight) = dY^T . x[:, K-r:] alone, against numpy fp64, on shapes that reach both block widths of the kernel (64
+    columns of dy per block once N / 32 * ceil(r / 64) > 512) with N not a multiple of the block, r not a multiple of 64
+    (a partly filled second j block, r > 128: a third) and M not a multiple of the 128-row slab."""
+    from qeft_amd import _lib, qeft_cuda
+    rng = np.random.default_rng(m + n)
+    x = rng.standard_normal((m, k)).astype(np.float16)
+    dy = (rng.standard_normal((m, n)) * 0.1).astype(np.float16)
+    dow = qeft_cuda.grad_oweight(torch.from_numpy(dy).to(DEV), torch.from_numpy(x).to(DEV), r)
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == ("grad_oweight_mfma_n64" if (n + 31) // 32 * ((r + 63) // 64) > 512 else "grad_oweight_mfma"), variant
+    ref = dy.astype(np.float64).T @ x[:, k - r:].astype(np.float64)
+    assert dow.shape == (n, r)
+    assert rel_err(dow.cpu().numpy(), ref) < REL_TOL
+
+
 def test_pack_oweight_device_bit_exact():
     from qeft_amd import qeft_cuda
     ow = (np.random.default_rng(0).standard_normal((64, 128))).astype(np.float16)
