@@ -1,0 +1,62 @@
+"""Randomised parity sweep of the C-ABI compute entries against the oracle (numpy) on one GPU: seeded shapes drawn from
+the whole accepted domain (N % 8, K % 64, group 32..256 dividing K, outlier count a multiple of 32, every batch tier),
+forward (GEMV / small-batch / GEMM tiers), dX and d(oweight).  One process, bounded sizes; prints one line per case and
+a summary.  A run is committed under profiles/ -- the fixed-shape tests in tests/ stay the gate."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from oracle import qeft_oracle as O
+from util import layer_to_torch, rel_err
+from qeft_amd import qeft_cuda, _lib
+DEV = "cuda:0"
+CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+LARGE = len(sys.argv) > 2 and sys.argv[2] == "large"       # shapes that reach the MFMA GEMV and the 128- / 256-row GEMM tiers
+rng = np.random.default_rng(20261004)
+fails, t0, seen = [], time.time(), {}
+for case in range(CASES):
+    k = 64 * int(rng.integers(16, 73) if LARGE else rng.integers(1, 41))      # 64 .. 2560 (large: 1024 .. 4608)
+    gs = [g for g in (32, 64, 128, 256) if k % g == 0]
+    g = int(rng.choice(gs))
+    n = 8 * int(rng.integers(64, 641) if LARGE else rng.integers(1, 161))     # 8 .. 1280 (large: 512 .. 5120)
+    r_choices = [r for r in (0, 32, 64, 96, 128, 160, 256) if r < k]
+    r = int(rng.choice(r_choices))
+    m = int(rng.choice([1, 4, 7, 64, 520, 1024, 1300, 2048, 2100] if LARGE else [1, 2, 3, 5, 7, 8, 9, 31, 64, 100, 129, 255, 300, 513, 1100]))
+    b = O.make_layer(n, k, r, g, seed=case)
+    t = layer_to_torch(b, DEV)
+    x = O.make_activation(m, k, r, seed=case)
+    dy = (np.random.default_rng(case).standard_normal((m, n)) * 0.1).astype(np.float16)
+    xt, dyt = torch.from_numpy(x).to(DEV), torch.from_numpy(dy).to(DEV)
+    ow = t.get("oweight") if r else None
+    errs = {}
+    try:
+        if m <= 7:
+            y = qeft_cuda.gemv_4bit_fused(xt, t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight_interleaved") if r else None,
+                                          None, None, None, m, n, k, g)
+        else:
+            y = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], ow)
+        v_f = _lib.last_variant()
+        dx = qeft_cuda.gemm_4bit_dx(dyt, t["qweight"], t["scales"], t["scaled_zeros"], ow)
+        v_dx = _lib.last_variant()
+        dow = qeft_cuda.grad_oweight(dyt, xt, r) if r else None
+        v_dow = _lib.last_variant() if r else "-"
+        torch.cuda.synchronize()
+        ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g)
+        dx_ref, dow_ref = O.quant_linear_backward(dy, x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, g)
+        errs["y"] = rel_err(y.cpu().numpy(), ref.astype(np.float64))
+        errs["dx"] = rel_err(dx.cpu().numpy(), dx_ref.astype(np.float64))
+        if r:
+            errs["dow"] = rel_err(dow.cpu().numpy(), dow_ref)
+        bad = {k_: v for k_, v in errs.items() if not (v < (2e-3 if k_ == "dx" else 1e-3))}
+    except Exception as e:      # a refused shape is a finding too
+        bad, v_f, v_dx, v_dow = {"exception": repr(e)}, "?", "?", "?"
+    for v in (v_f, v_dx, v_dow):
+        seen[v] = seen.get(v, 0) + 1
+    line = f"case {case:3d} n={n:5d} k={k:5d} g={g:3d} r={r:3d} m={m:4d}  {v_f:24s} {v_dx:12s} {v_dow:22s} " + " ".join(f"{a}={v:.1e}" for a, v in errs.items())
+    print(line + ("   FAIL " + str(bad) if bad else ""), flush=True)
+    if bad:
+        fails.append((case, n, k, g, r, m, bad))
+print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
+for f in fails:
+    print("FAIL", f)
+sys.exit(1 if fails else 0)
