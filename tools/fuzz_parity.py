@@ -14,6 +14,31 @@ CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 LARGE = len(sys.argv) > 2 and sys.argv[2] == "large"       # shapes that reach the MFMA GEMV and the 128- / 256-row GEMM tiers
 rng = np.random.default_rng(20261004)
 fails, t0, seen = [], time.time(), {}
+if len(sys.argv) > 2 and sys.argv[2] == "v3":
+    # the engine's decode GEMV (qeft_decode_linear) on random shapes of its own domain: N % 16, K % 128, group 128, r in {0, 128}
+    import types
+    for case in range(CASES):
+        n = 16 * int(rng.integers(1, 901))
+        k = 128 * int(rng.integers(1, 91))
+        r = int(rng.choice([0, 128])) if k > 128 else 0
+        b = O.make_layer(n, k, r, 128, seed=case, bias=bool(case & 1))
+        t = layer_to_torch(b, DEV)
+        l = types.SimpleNamespace(qweight=t["qweight"], scales=t["scales"], scaled_zeros=t["scaled_zeros"], oweight=t.get("oweight"),
+                                  bias=t.get("bias"), outfeatures=n, infeatures=k, group_size=128, outlierfeatures=r)
+        l.sz_packed = qeft_cuda.pack_scales(l.scales, l.scaled_zeros, n, k, 128)
+        x = O.make_activation(1, k, r, seed=case)
+        y = qeft_cuda.decode_linear(torch.from_numpy(x[0]).to(DEV), l)
+        v = _lib.last_variant()
+        torch.cuda.synchronize()
+        ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, b.get("bias"), 128)
+        e = rel_err(y.cpu().numpy()[None], ref.astype(np.float64))
+        seen[v] = seen.get(v, 0) + 1
+        ok = e < 1e-3
+        print(f"case {case:3d} n={n:5d} k={k:5d} r={r:3d} bias={case & 1}  {v:10s} y={e:.1e}" + ("" if ok else "   FAIL"), flush=True)
+        if not ok:
+            fails.append((case, n, k, r, e))
+    print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
+    sys.exit(1 if fails else 0)
 for case in range(CASES):
     k = 64 * int(rng.integers(16, 73) if LARGE else rng.integers(1, 41))      # 64 .. 2560 (large: 1024 .. 4608)
     gs = [g for g in (32, 64, 128, 256) if k % g == 0]
