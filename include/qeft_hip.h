@@ -87,6 +87,14 @@ int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const v
                  const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size,
                  int n_out, qeft_stream_t stream);
 
+/* qeft_gemm_w4 with the MLP's activation in its epilogue:  y = silu(gate) * (x . Wdeq^T + bias), gate fp16 [m, n] -- the
+ * reference's up_proj GEMM followed by act_fn(gate) * up (modeling_llama's LlamaMLP around qlinear.py:244-271) in one
+ * launch on the 256-row tier (variant "gemm_v3_256x128+silu"), the GEMM plus qeft_silu_mul in place on the others; the
+ * same rounding either way (the product is rounded to fp16 before the activation).  n % 8 == 0; y may not alias gate. */
+int qeft_gemm_w4_silu_mul(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                          const void* oweight, const void* bias, const void* gate, void* y, int m, int n, int k,
+                          int group_size, int n_out, qeft_stream_t stream);
+
 /* The same with a scratch buffer for mid-size m: when the 128x128 tiling of [m, n] leaves most of the chip idle the
  * K loop is cut into S parts (fp32 partial tiles in `workspace`, summed in a fixed order by a second small launch --
  * deterministic).  qeft_gemm_w4_workspace_bytes() is the size that enables it for a shape (0: no split would be

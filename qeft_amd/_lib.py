@@ -29,6 +29,7 @@ SIGNATURES = {
     "qeft_pack_scales": [_p, _p, _p, _i, _i, _i, _p],
     "qeft_gemm_w4": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_workspace_bytes": [_i, _i, _i, _i],
+    "qeft_gemm_w4_silu_mul": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_ws": [_p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_dx": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_dx_workspace_bytes": [_i, _i, _i],

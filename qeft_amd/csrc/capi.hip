@@ -1,5 +1,7 @@
 // extern "C" entry points declared in include/qeft_hip.h: argument validation + dispatch.
 #include <hip/hip_runtime.h>
+
+#include <cstring>
 #include <stdint.h>
 
 #include "../../include/qeft_hip.h"
@@ -46,7 +48,7 @@ hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream
 hipError_t pack_scales_launch(const void* scales, const void* zeros, void* out, int N, int ngroups, hipStream_t st);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
-                          void* workspace = nullptr, size_t workspace_bytes = 0);
+                          void* workspace = nullptr, size_t workspace_bytes = 0, const void* silu_gate = nullptr);
 int gemm_w4_split(int M, int N, int K, int n_out);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace = nullptr,
@@ -170,7 +172,7 @@ int qeft_gemv_w4_qeft(const void* x, const void* qweight, const void* scales, co
 
 static int gemm_impl(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                      const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size, int n_out,
-                     qeft_stream_t stream, void* workspace, size_t workspace_bytes) {
+                     qeft_stream_t stream, void* workspace, size_t workspace_bytes, const void* silu_gate = nullptr) {
     if (m < 1) return QEFT_ERR_SHAPE;
     if (!oweight) n_out = 0;
     if (int e = check_common(n, k, group_size, n_out)) return e;
@@ -199,13 +201,26 @@ static int gemm_impl(const void* x, const void* qweight, const void* scales, con
         if (e != hipErrorNotSupported) return finish(e);
     }
     return finish(qeft::gemm_w4_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out,
-                                       (hipStream_t)stream, workspace, workspace_bytes));
+                                       (hipStream_t)stream, workspace, workspace_bytes, silu_gate));
 }
 
 int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                  const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size, int n_out,
                  qeft_stream_t stream) {
     return gemm_impl(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out, stream, nullptr, 0);
+}
+
+int qeft_gemm_w4_silu_mul(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                          const void* oweight, const void* bias, const void* gate, void* y, int m, int n, int k,
+                          int group_size, int n_out, qeft_stream_t stream) {
+    if (!gate) return QEFT_ERR_NULL;
+    if (n % 8 != 0 || (long long)m * n > 0x7fffffffLL) return QEFT_ERR_SHAPE;
+    if (!aligned16(gate) || !aligned16(y)) return QEFT_ERR_ALIGN;
+    const int e = gemm_impl(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out, stream, nullptr, 0,
+                            gate);
+    if (e != QEFT_OK || strstr(qeft::g_last_variant, "+silu")) return e;
+    // a tier without the fused epilogue: the product is in y, finish in place
+    return finish(qeft::silu_mul_launch(gate, y, y, m * n, (hipStream_t)stream));
 }
 
 long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {

@@ -464,11 +464,14 @@ __device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32
 
 // ABL (lab only, QEFT_GEMM_ABL): 1 = the loader waves issue no DMA, 2 = the compute waves skip their k-tile bodies -- wrong
 // results, but the two timings say which side of the block sets the pace (profiles/r02_gemm_v3_ablation.txt).
-template <bool OUTL, int ABL = 0>
+// SILU: y = silu(gate) * (x . W^T + bias) with gate [M][N] fp16 -- the MLP's SiLU(gate) * up formed in the up_proj launch's
+// epilogue (same rounding as the unfused pair: the product is rounded to fp16 first, then silu_mul_kernel's formula).
+template <bool OUTL, int ABL = 0, bool SILU = false>
 __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
-                                                           f16* __restrict__ y, int M, int N, int K, int G, int n_out, int NB) {
+                                                           f16* __restrict__ y, int M, int N, int K, int G, int n_out, int NB,
+                                                           const f16* __restrict__ gate) {
     // 8 waves, two per SIMD with fixed roles: waves 0..3 compute (wave w: columns 32 w .. 32 w + 31 of the tile, all 256 rows),
     // waves 4..7 load (wave 4 + l: activation pieces 8 l .. 8 l + 7, the packed weights of compute wave l, scales / zeros).
     // An LDS-DMA instruction holds its wave for 100-200 cycles at issue; in the compute waves' own stream (first version)
@@ -710,6 +713,21 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // row segments, 16 bytes per lane: the direct form (2-byte stores, 64 bytes per row per instruction) cost ~10 us per block.
     __builtin_amdgcn_s_barrier();              // every compute wave is done with the ring (the loader waves have exited)
     asm volatile("" ::: "memory");
+    // SILU: the gate segments of the 16 row groups this lane stores below, fetched four groups at a time, the first two
+    // batches before the tile goes to LDS (clamped addresses, unconditional loads)
+    u32x4 ga[4], gb[4];
+    auto gate_load = [&](int grp, u32x4(&dst)[4]) {
+        const int n0c = min(bn0 + (lane & 15) * 8, N - 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(bm0 + wave * 64 + (grp * 4 + j) * 4 + (lane >> 4), M - 1);
+            dst[j] = *(const u32x4*)(gate + (size_t)m * N + n0c);
+        }
+    };
+    if (SILU) {
+        gate_load(0, ga);
+        gate_load(1, gb);
+    }
     {
         const float bv = bias ? (float)bias[ncol] : 0.f;
         uint8_t* const col = lds + nloc * 2;
@@ -721,7 +739,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
+    if (!SILU) {
         const int ch = lane & 15, n0 = bn0 + ch * 8;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
@@ -735,6 +753,26 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                 for (int j = 0; j < 8 && n0 + j < N; ++j) dst[j] = hv[j];
             }
         }
+    } else {                                   // N % 8 == 0 (launcher)
+        const int ch = lane & 15, n0 = bn0 + ch * 8;
+        auto put = [&](int grp, const u32x4(&g)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wave * 64 + (grp * 4 + j) * 4 + (lane >> 4), m = bm0 + row;
+                if (m >= M || n0 >= N) continue;
+                const h8 u = __builtin_bit_cast(h8, *(const u32x4*)(lds + row * G3_YP + ch * 16)), gv = __builtin_bit_cast(h8, g[j]);
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)(silu_f32((float)gv[e]) * (float)u[e]);
+                *(h8*)(y + (size_t)m * N + n0) = o;
+            }
+        };
+        put(0, ga);
+        gate_load(2, ga);
+        put(1, gb);
+        gate_load(3, gb);
+        put(2, ga);
+        put(3, gb);
     }
     if (ABL == 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -770,7 +808,7 @@ int gemm_w4_split(int M, int N, int K, int n_out) {
 
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
-                          void* workspace, size_t workspace_bytes) {
+                          void* workspace, size_t workspace_bytes, const void* silu_gate) {
     const bool outl = ow && n_out > 0;
     // 256 x 128 tiles, one wave per SIMD (gemm_w4_kernel_v3), when they give (nearly) every CU a block: the M >= 2048 tier
     // of a prefill / fine-tune step.  QEFT_GEMM_V3 = 0 / 1 forces the choice (A/B).
@@ -779,15 +817,19 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         const int mb = (M + G3_BM - 1) / G3_BM, nb = (N + G3_BN - 1) / G3_BN;
         const bool ok3 = K / BK >= G3_BST && K % BK == 0 && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && G >= 64 &&
                          N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
-        if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024))) {
+        if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024)) && (!silu_gate || N % 8 == 0)) {
             auto go3 = [&](auto kern) -> hipError_t {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_SMEM);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(mb * nb), dim3(512), G3_SMEM, st, (const f16*)x, (const uint8_t*)qw,
                                    (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
-                                   (f16*)y, M, N, K, G, outl ? n_out : 0, nb);
+                                   (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)silu_gate);
                 return hipGetLastError();
             };
+            if (silu_gate) {
+                g_last_variant = "gemm_v3_256x128+silu";
+                return outl ? go3(gemm_w4_kernel_v3<true, 0, true>) : go3(gemm_w4_kernel_v3<false, 0, true>);
+            }
             g_last_variant = "gemm_v3_256x128";
 #ifdef QEFT_LAB      // lab builds only (QEFT_BUILD_LAB=1 python -m qeft_amd.build): ablations / time stamps, wrong results by design
             static const int abl = getenv("QEFT_GEMM_ABL") ? atoi(getenv("QEFT_GEMM_ABL")) : 0;

@@ -210,13 +210,6 @@ def _add_rmsnorm(x, add, gamma, eps):
     return h, y
 
 
-def _silu_mul(gate, up):
-    out = torch.empty_like(gate)
-    _lib.check(_lib.lib().qeft_silu_mul(gate.data_ptr(), up.data_ptr(), out.data_ptr(), gate.numel(),
-                                        torch.cuda.current_stream(gate.device).cuda_stream))
-    return out
-
-
 @torch.no_grad()
 def prefill(model: "QuantLlama", tokens, engine=None):
     """Batched forward over T prompt tokens through the packed QuantLinears: T >= 8 rows take the MFMA GEMM path
@@ -262,7 +255,7 @@ def prefill(model: "QuantLlama", tokens, engine=None):
                                                              vv.transpose(0, 1)[None], is_causal=True)[0]    # [H, T, 128]
         a = a.transpose(0, 1).reshape(T, s.hidden).contiguous()
         h, x = _add_rmsnorm(h, at.o_proj(a), L.post_attention_layernorm, s.rms_eps)     # o_proj gathers its own column order
-        delta = mlp.down_proj(_silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
+        delta = mlp.down_proj(mlp.up_proj.forward_silu_mul(x, mlp.gate_proj(x)))     # SiLU(gate) * up in the up_proj GEMM's epilogue
     if engine is not None:
         engine.set_position(T)
     _, hn = _add_rmsnorm(h, delta, model.model.norm, s.rms_eps)

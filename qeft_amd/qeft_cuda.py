@@ -112,6 +112,34 @@ def gemm_4bit_qeft(in_feats, kernel, scales, zeros, oweights, bias=None):
 _GEMM_WS = {}   # (device index, stream) -> fp32 scratch of the split-K GEMM
 
 
+def gemm_4bit_qeft_silu_mul(in_feats, kernel, scales, zeros, oweights, gate, bias=None):
+    """silu(gate) * gemm_4bit_qeft(in_feats, ...): the MLP's act_fn(gate_proj(x)) * up_proj(x) with the activation in the
+    up_proj GEMM's epilogue (one launch on the 256-row tier; GEMM + qeft_silu_mul in place otherwise).  Extension."""
+    _check_common(in_feats, kernel, scales, zeros)
+    x = in_feats.contiguous()
+    k = x.shape[-1]
+    n = kernel.shape[0] * 4
+    m = x.numel() // k
+    _need(kernel.shape[1] == k, f"kernel has K={kernel.shape[1]}, in_feats has K={k}")
+    _need(gate.dtype == torch.float16 and gate.is_contiguous() and gate.numel() == m * n and gate.device == x.device,
+          "gate must be a contiguous Half [..., N] tensor of the output's shape")
+    group = k // scales.shape[0]
+    n_out = 0
+    if oweights is not None:
+        _need(oweights.dtype == torch.float16 and oweights.is_contiguous() and oweights.shape[0] == n,
+              "oweights must be a contiguous Half [N, r] tensor")
+        n_out = oweights.shape[1]
+    out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(in_feats.device):
+        _lib.check(_lib.lib().qeft_gemm_w4_silu_mul(x.data_ptr(), kernel.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                                    oweights.data_ptr() if n_out else None,
+                                                    bias.data_ptr() if bias is not None else None, gate.data_ptr(),
+                                                    out.data_ptr(), m, n, k, group, n_out, _stream(x)))
+    return out
+
+
 # ---- entry points beyond the reference's module (used by QuantLinear's fused paths and the backward) ----
 
 def gemv_4bit_fused(in_feats, kernel, scaling_factors, zeros, oweight_il, bias, reorder_ids, residual, m, n, k,

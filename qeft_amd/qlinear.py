@@ -368,6 +368,19 @@ class QuantLinear(nn.Module):
             y += torch.nn.functional.linear(inputs[..., -self.outlierfeatures:], self._outlier_weight_f16())
         return y + self.bias if self.bias is not None else y
 
+    def forward_silu_mul(self, x, gate):
+        """silu(gate) * self(x), inference: the MLP's act_fn(gate_proj(x)) * up_proj(x) with the activation formed in this
+        layer's GEMM epilogue where the launch has one (>= 8 rows on the fused path; same rounding as the unfused pair).
+        Extension: the reference multiplies in torch (modeling_llama's LlamaMLP around QuantLinear.forward)."""
+        seq_len = x.numel() // x.shape[-1]
+        if self.training or not self.fused or seq_len < 8 or self.forward == self.forward_outlier_out_proj:
+            y = self.forward(x)
+            return torch.nn.functional.silu(gate.float()).mul_(y.float()).to(y.dtype)
+        r = self.outlierfeatures
+        qw = self._qweight4() if self.bits == 3 else self.qweight
+        return qeft_cuda.gemm_4bit_qeft_silu_mul(x, qw, self.scales, self.scaled_zeros,
+                                                 self._outlier_weight_f16() if r > 0 else None, gate.contiguous(), self.bias)
+
     def forward_normal(self, x):
         if self.bits == 3:
             return self._forward_w3(x, False)

@@ -117,6 +117,35 @@ def test_doweight_block_widths_ragged(m, n, k, r):
     assert rel_err(dow.cpu().numpy(), ref) < REL_TOL
 
 
+@pytest.mark.parametrize("m,n,k,r,fused", [(2048, 3584, 512, 128, True), (2000, 3592, 384, 0, True), (1100, 7176, 448, 64, True),
+                                            (64, 512, 512, 128, False), (300, 1024, 256, 0, False)])
+def test_gemm_silu_mul_epilogue(m, n, k, r, fused):
+    """silu(gate) * (x . W^T + bias) from one launch on the 256-row tier == the GEMM followed by qeft_silu_mul, bit for bit
+    (the product is rounded to fp16 before the activation in both), and within tolerance of float64; other tiers take the
+    two-launch form inside the same entry."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, 128 if k % 128 == 0 else 64, seed=m + n, bias=True)
+    g = 128 if k % 128 == 0 else 64
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=m)
+    gate = np.random.default_rng(n).standard_normal((m, n)).astype(np.float16)
+    xt, gt = torch.from_numpy(x).to(DEV), torch.from_numpy(gate).to(DEV)
+    ow = t.get("oweight") if r else None
+    y = qeft_cuda.gemm_4bit_qeft_silu_mul(xt, t["qweight"], t["scales"], t["scaled_zeros"], ow, gt, t["bias"])
+    variant = _lib.last_variant()
+    up = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], ow, t["bias"])
+    two = torch.empty_like(up)
+    _lib.check(_lib.lib().qeft_silu_mul(gt.data_ptr(), up.data_ptr(), two.data_ptr(), up.numel(),
+                                        torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert ("+silu" in variant) == fused, variant
+    assert torch.equal(y, two)
+    ref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None,
+                         bufs["bias"], g).astype(np.float64)
+    g64 = gate.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), g64 / (1 + np.exp(-g64)) * ref) < REL_TOL
+
+
 def test_pack_oweight_device_bit_exact():
     from qeft_amd import qeft_cuda
     ow = (np.random.default_rng(0).standard_normal((64, 128))).astype(np.float16)
