@@ -95,6 +95,17 @@ int qeft_gemm_w4_silu_mul(const void* x, const void* qweight, const void* scales
                           const void* oweight, const void* bias, const void* gate, void* y, int m, int n, int k,
                           int group_size, int n_out, qeft_stream_t stream);
 
+/* gate_proj and up_proj of the MLP as ONE launch: qweight / scales / scaled_zeros / oweight / bias hold the two linears'
+ * rows interleaved in blocks of 64 (rows 128 b .. 128 b + 63 = gate rows 64 b .., rows 128 b + 64 .. = up rows 64 b ..: a
+ * permutation of whole checkpoint rows, built at load time by qeft_amd/fuse.py, never saved), n2 = both linears' rows;
+ * y [m, n2 / 2] = silu(x . Wgate^T + bgate) * (x . Wup^T + bup), the two products rounded to fp16 first (bit-equal to the
+ * separate launches).  qeft_gemm_w4_gateup_supported() says whether a shape is taken (n2 % 128 == 0, K >= 384,
+ * group a power of two >= 64, n_out % 64 == 0); otherwise use the two linears and qeft_gemm_w4_silu_mul. */
+int qeft_gemm_w4_gateup_supported(int m, int n2, int k, int group_size, int n_out);
+int qeft_gemm_w4_gateup(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                        const void* oweight, const void* bias, void* y, int m, int n2, int k, int group_size, int n_out,
+                        qeft_stream_t stream);
+
 /* The same with a scratch buffer for mid-size m: when the 128x128 tiling of [m, n] leaves most of the chip idle the
  * K loop is cut into S parts (fp32 partial tiles in `workspace`, summed in a fixed order by a second small launch --
  * deterministic).  qeft_gemm_w4_workspace_bytes() is the size that enables it for a shape (0: no split would be
@@ -236,8 +247,11 @@ int qeft_token_begin_norm(const void* embed, const void* tok, const void* rope_t
                           const void* gamma, void* h_norm, float* ssq_out, int hidden, int vocab, int max_seq,
                           qeft_stream_t stream);
 int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hidden, float eps, qeft_stream_t stream); /* qeft_rmsnorm on an fp32 input */
-/* qeft_rope_rows (prefill helper): NeoX rotary of x [t][n_heads][128] fp16 in place, cos_tab / sin_tab fp32 [t][64]. */
-int qeft_rope_rows(void* x, const void* cos_tab, const void* sin_tab, int t, int n_heads, qeft_stream_t stream);
+/* qeft_rope_rows (prefill helper): NeoX rotary of the first n_heads heads of every row of x (fp16, rows row_stride elements
+ * apart, a head = 128 consecutive elements; row_stride = n_heads * 128 for a plain [t][n_heads][128] tensor, the width of the
+ * fused q|k|v output for its q and k heads) in place, cos_tab / sin_tab fp32 [t][64]. */
+int qeft_rope_rows(void* x, const void* cos_tab, const void* sin_tab, int t, int n_heads, int row_stride,
+                   qeft_stream_t stream);
 /* qeft_lm_head_f16 (decode harness, token tail): logits[vocab] (fp16) = weight[vocab][hidden] (fp16, the unquantized lm_head)
  * . fp16(rmsnorm(h32) * gamma) -- the final norm of qeft_rmsnorm_f32 and the head GEMV in one launch, fp32 accumulation.
  * hidden in {512, 1024, 2048, 4096, 5120, 8192}. */

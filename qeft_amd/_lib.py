@@ -30,6 +30,8 @@ SIGNATURES = {
     "qeft_gemm_w4": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_workspace_bytes": [_i, _i, _i, _i],
     "qeft_gemm_w4_silu_mul": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemm_w4_gateup_supported": [_i, _i, _i, _i, _i],
+    "qeft_gemm_w4_gateup": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_ws": [_p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_dx": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_gemm_w4_dx_workspace_bytes": [_i, _i, _i],
@@ -57,7 +59,7 @@ SIGNATURES = {
     "qeft_token_begin_norm": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_rmsnorm_f32": [_p, _p, _p, _i, _i, ctypes.c_float, _p],
     "qeft_lm_head_f16": [_p, _p, _p, _p, _i, _i, ctypes.c_float, _p],
-    "qeft_rope_rows": [_p, _p, _p, _i, _i, _p],
+    "qeft_rope_rows": [_p, _p, _p, _i, _i, _i, _p],
     "qeft_residual_norm": [_p, _p, _p, _p, _p, _p, _i, _p],
     "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

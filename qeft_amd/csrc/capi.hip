@@ -20,7 +20,7 @@ int token_begin_norm_blocks(int hidden);
 hipError_t residual_norm_launch(const void* h, const void* add, const void* gamma, void* h_out, void* hnorm, float* ssq_out,
                                 int hidden, hipStream_t st);
 hipError_t rmsnorm_f32_launch(const void* x, const void* gamma, void* y, int m, int H, float eps, hipStream_t st);
-hipError_t rope_rows_launch(void* x, const void* cs, const void* sn, int T, int H, hipStream_t st);
+hipError_t rope_rows_launch(void* x, const void* cs, const void* sn, int T, int H, int row_stride, hipStream_t st);
 hipError_t lm_head_f16_launch(const void* h32, const void* gamma, const void* W, void* logits, int H, int vocab, float eps,
                               hipStream_t st);
 hipError_t gemv_w4_dispatch(const GemvArgs& a, int m, hipStream_t st);
@@ -46,6 +46,8 @@ hipError_t dequant_w4_launch(const void* qw, const void* scales, const void* zer
                              int K, int G, int n_out, hipStream_t st);
 hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream_t st);
 hipError_t pack_scales_launch(const void* scales, const void* zeros, void* out, int N, int ngroups, hipStream_t st);
+extern const void* const kSiluPair64;
+bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
                           void* workspace = nullptr, size_t workspace_bytes = 0, const void* silu_gate = nullptr);
@@ -221,6 +223,22 @@ int qeft_gemm_w4_silu_mul(const void* x, const void* qweight, const void* scales
     if (e != QEFT_OK || strstr(qeft::g_last_variant, "+silu")) return e;
     // a tier without the fused epilogue: the product is in y, finish in place
     return finish(qeft::silu_mul_launch(gate, y, y, m * n, (hipStream_t)stream));
+}
+
+int qeft_gemm_w4_gateup_supported(int m, int n2, int k, int group_size, int n_out) {
+    if (m < 1 || check_common(n2, k, group_size, n_out) != QEFT_OK || (long long)m * n2 > 0x7fffffffLL) return 0;
+    return qeft::gemm_w4_pair64_ok(m, n2, k, group_size, n_out) ? 1 : 0;
+}
+
+int qeft_gemm_w4_gateup(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
+                        const void* oweight, const void* bias, void* y, int m, int n2, int k, int group_size, int n_out,
+                        qeft_stream_t stream) {
+    if (!oweight) n_out = 0;
+    if (!qeft_gemm_w4_gateup_supported(m, n2, k, group_size, n_out)) return QEFT_ERR_SHAPE;
+    if (!x || !qweight || !scales || !scaled_zeros || !y) return QEFT_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight) || !aligned16(y) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
+    return finish(qeft::gemm_w4_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n2, k, group_size, n_out,
+                                       (hipStream_t)stream, nullptr, 0, qeft::kSiluPair64));
 }
 
 long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {
@@ -436,10 +454,11 @@ int qeft_rmsnorm_f32(const void* x32, const void* gamma, void* y, int m, int hid
     return finish(qeft::rmsnorm_f32_launch(x32, gamma, y, m, hidden, eps, (hipStream_t)stream));
 }
 
-int qeft_rope_rows(void* x, const void* cos_tab, const void* sin_tab, int t, int n_heads, qeft_stream_t stream) {
-    if (t < 1 || n_heads < 1) return QEFT_ERR_SHAPE;
+int qeft_rope_rows(void* x, const void* cos_tab, const void* sin_tab, int t, int n_heads, int row_stride,
+                   qeft_stream_t stream) {
+    if (t < 1 || n_heads < 1 || row_stride < n_heads * 128) return QEFT_ERR_SHAPE;
     if (!x || !cos_tab || !sin_tab) return QEFT_ERR_NULL;
-    return finish(qeft::rope_rows_launch(x, cos_tab, sin_tab, t, n_heads, (hipStream_t)stream));
+    return finish(qeft::rope_rows_launch(x, cos_tab, sin_tab, t, n_heads, row_stride, (hipStream_t)stream));
 }
 
 int qeft_lm_head_f16(const void* h32, const void* gamma, const void* weight, void* logits, int hidden, int vocab, float eps,

@@ -495,19 +495,19 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restric
 // math, one rounding -- the arithmetic of the decode kernel's rope).  Prefill helper: torch's float / mul / cat sequence for
 // the same was ~0.13 ms per layer at T = 2048.
 __global__ __launch_bounds__(256) void rope_rows_kernel(f16* __restrict__ x, const float* __restrict__ cs,
-                                                        const float* __restrict__ sn, int H) {
+                                                        const float* __restrict__ sn, int H, int row_stride) {
     const int t = blockIdx.x, i = threadIdx.x & 63;
     const float c = cs[(size_t)t * 64 + i], s = sn[(size_t)t * 64 + i];
     for (int h = threadIdx.x >> 6; h < H; h += 4) {
-        f16* p = x + ((size_t)t * H + h) * 128;
+        f16* p = x + (size_t)t * row_stride + h * 128;
         const float a = (float)p[i], b = (float)p[i + 64];
         p[i] = (f16)(a * c - b * s);
         p[i + 64] = (f16)(b * c + a * s);
     }
 }
 
-hipError_t rope_rows_launch(void* x, const void* cs, const void* sn, int T, int H, hipStream_t st) {
-    hipLaunchKernelGGL(rope_rows_kernel, dim3(T), dim3(256), 0, st, (f16*)x, (const float*)cs, (const float*)sn, H);
+hipError_t rope_rows_launch(void* x, const void* cs, const void* sn, int T, int H, int row_stride, hipStream_t st) {
+    hipLaunchKernelGGL(rope_rows_kernel, dim3(T), dim3(256), 0, st, (f16*)x, (const float*)cs, (const float*)sn, H, row_stride);
     return hipGetLastError();
 }
 

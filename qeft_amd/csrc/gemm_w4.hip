@@ -464,9 +464,12 @@ __device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32
 
 // ABL (lab only, QEFT_GEMM_ABL): 1 = the loader waves issue no DMA, 2 = the compute waves skip their k-tile bodies -- wrong
 // results, but the two timings say which side of the block sets the pace (profiles/r02_gemm_v3_ablation.txt).
-// SILU: y = silu(gate) * (x . W^T + bias) with gate [M][N] fp16 -- the MLP's SiLU(gate) * up formed in the up_proj launch's
+// EPI 1: y = silu(gate) * (x . W^T + bias) with gate [M][N] fp16 -- the MLP's SiLU(gate) * up formed in the up_proj launch's
 // epilogue (same rounding as the unfused pair: the product is rounded to fp16 first, then silu_mul_kernel's formula).
-template <bool OUTL, int ABL = 0, bool SILU = false>
+// EPI 2: W holds gate and up interleaved in blocks of 64 rows (fuse.pair64_gemm_operand), so that columns 0..63 of a block's
+// tile are gate and 64..127 the same columns of up: y [M][N/2] = silu(tile[:, :64]) * tile[:, 64:], one launch for both
+// linears, no gate round trip through HBM.
+template <bool OUTL, int ABL = 0, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             dst[j] = *(const u32x4*)(gate + (size_t)m * N + n0c);
         }
     };
-    if (SILU) {
+    if (EPI == 1) {
         gate_load(0, ga);
         gate_load(1, gb);
     }
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (!SILU) {
+    if (EPI == 0) {
         const int ch = lane & 15, n0 = bn0 + ch * 8;
 #pragma unroll 4
         for (int i = 0; i < 16; ++i) {
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                 for (int j = 0; j < 8 && n0 + j < N; ++j) dst[j] = hv[j];
             }
         }
-    } else {                                   // N % 8 == 0 (launcher)
+    } else if (EPI == 1) {                     // N % 8 == 0 (launcher)
         const int ch = lane & 15, n0 = bn0 + ch * 8;
         auto put = [&](int grp, const u32x4(&g)[4]) {
 #pragma unroll
@@ -773,6 +776,19 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         gate_load(3, gb);
         put(2, ga);
         put(3, gb);
+    } else {                                   // EPI 2: N % 128 == 0 (launcher); 8 lanes per row of 64 outputs
+        const int ch = lane & 7, nh = N >> 1, n0 = (bn0 >> 1) + ch * 8;
+#pragma unroll 4
+        for (int i = 0; i < 8; ++i) {
+            const int row = wave * 64 + i * 8 + (lane >> 3), m = bm0 + row;
+            if (m >= M) continue;
+            const h8 gv = __builtin_bit_cast(h8, *(const u32x4*)(lds + row * G3_YP + ch * 16));
+            const h8 u = __builtin_bit_cast(h8, *(const u32x4*)(lds + row * G3_YP + 128 + ch * 16));
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(silu_f32((float)gv[e]) * (float)u[e]);
+            *(h8*)(y + (size_t)m * nh + n0) = o;
+        }
     }
     if (ABL == 6) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -806,6 +822,15 @@ int gemm_w4_split(int M, int N, int K, int n_out) {
     return s < 2 ? 1 : s;
 }
 
+// silu_gate == kSiluPair64: the paired-halves epilogue (EPI 2) instead of an external gate tensor
+extern const void* const kSiluPair64 = (const void*)(uintptr_t)1;
+
+// shapes the paired gate|up launch takes (n2 = both linears' rows): the 256-row kernel's domain, whole 128-column tiles
+bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out) {
+    return M >= 1 && n2 % 128 == 0 && K / BK >= G3_BST && K % BK == 0 && n_out % 64 == 0 && (G & (G - 1)) == 0 && G >= 64 &&
+           (size_t)M * K * 2 < (1ull << 32) && (size_t)(n2 / 4) * K * 2 < (1ull << 32);
+}
+
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
                           void* workspace, size_t workspace_bytes, const void* silu_gate) {
@@ -817,7 +842,9 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         const int mb = (M + G3_BM - 1) / G3_BM, nb = (N + G3_BN - 1) / G3_BN;
         const bool ok3 = K / BK >= G3_BST && K % BK == 0 && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && G >= 64 &&
                          N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
-        if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024)) && (!silu_gate || N % 8 == 0)) {
+        if (silu_gate == kSiluPair64 && !(ok3 && N % 128 == 0)) return hipErrorNotSupported;     // capi checks gemm_w4_pair64_ok first
+        if (ok3 && (silu_gate == kSiluPair64 || force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024)) &&
+            (!silu_gate || N % 8 == 0)) {
             auto go3 = [&](auto kern) -> hipError_t {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_SMEM);
                 if (e != hipSuccess) return e;
@@ -826,9 +853,13 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                                    (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)silu_gate);
                 return hipGetLastError();
             };
+            if (silu_gate == kSiluPair64) {
+                g_last_variant = "gemm_v3_256x128+silu_pair";
+                return outl ? go3(gemm_w4_kernel_v3<true, 0, 2>) : go3(gemm_w4_kernel_v3<false, 0, 2>);
+            }
             if (silu_gate) {
                 g_last_variant = "gemm_v3_256x128+silu";
-                return outl ? go3(gemm_w4_kernel_v3<true, 0, true>) : go3(gemm_w4_kernel_v3<false, 0, true>);
+                return outl ? go3(gemm_w4_kernel_v3<true, 0, 1>) : go3(gemm_w4_kernel_v3<false, 0, 1>);
             }
             g_last_variant = "gemm_v3_256x128";
 #ifdef QEFT_LAB      // lab builds only (QEFT_BUILD_LAB=1 python -m qeft_amd.build): ablations / time stamps, wrong results by design

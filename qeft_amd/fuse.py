@@ -114,3 +114,46 @@ def column_shard(layer, owned_cols):
                          outfeatures=n, infeatures=kp_q + r, group_size=g, outlierfeatures=r, first_group=g0)
     local = torch.where(owned < kq, owned - 128 * g0, kp_q + owned - kq).to(torch.int32)
     return op, local
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GEMM-side operands of the batched prompt pass (llama.prefill): the checkpoint layout itself (qweight [N/4, K] int16,
+# scales / scaled_zeros [K/g, N], oweight [N, r]), several linears in one launch.  Derived at load time, never saved.
+
+def _gemm_operand(qweight, scales, zeros, oweight, bias, n, k, g, r):
+    return SimpleNamespace(qweight=qweight.contiguous(), scales=scales.contiguous(), scaled_zeros=zeros.contiguous(),
+                           oweight=oweight.contiguous() if oweight is not None else None,
+                           bias=bias.contiguous() if bias is not None else None,
+                           outfeatures=n, infeatures=k, group_size=g, outlierfeatures=r)
+
+
+def _check_gemm(layers):
+    k, g, r = _check(layers)
+    assert all(_bits(l) == 4 for l in layers), "GEMM-side fusions read the 4-bit checkpoint layout"
+    return k, g, r
+
+
+def concat_gemm_operand(layers):
+    """q|k|v for the GEMM: the linears' rows one after the other (they read the same x): one launch, y [M, sum N]."""
+    k, g, r = _check_gemm(layers)
+    return _gemm_operand(torch.cat([l.qweight for l in layers], 0), torch.cat([l.scales for l in layers], 1),
+                         torch.cat([l.scaled_zeros for l in layers], 1),
+                         torch.cat([_plain_oweight(l) for l in layers], 0) if r else None,
+                         torch.cat([l.bias for l in layers], 0) if layers[0].bias is not None else None,
+                         sum(l.outfeatures for l in layers), k, g, r)
+
+
+def pair64_gemm_operand(gate, up):
+    """gate|up for qeft_gemm_w4_gateup: rows interleaved in blocks of 64 -- operand rows 128 b .. 128 b + 63 = gate rows
+    64 b .., rows 128 b + 64 .. = up rows 64 b .. -- so that a 128-column tile of the GEMM holds the same 64 columns of both
+    linears and SiLU(gate) * up is its epilogue.  64 rows = 16 qweight rows: whole checkpoint rows move, no nibble is touched."""
+    k, g, r = _check_gemm([gate, up])
+    n = gate.outfeatures
+    assert up.outfeatures == n and n % 64 == 0
+    il_rows = lambda a, b, rows: torch.stack([a.reshape(n // 64, rows, -1), b.reshape(n // 64, rows, -1)], 1).reshape(2 * a.shape[0], -1)   # noqa: E731
+    il_cols = lambda a, b: torch.stack([a.reshape(a.shape[0], n // 64, 64), b.reshape(b.shape[0], n // 64, 64)], 2).reshape(a.shape[0], 2 * n)   # noqa: E731
+    return _gemm_operand(il_rows(gate.qweight, up.qweight, 16), il_cols(gate.scales, up.scales),
+                         il_cols(gate.scaled_zeros, up.scaled_zeros),
+                         il_rows(_plain_oweight(gate), _plain_oweight(up), 64) if r else None,
+                         il_rows(gate.bias[:, None], up.bias[:, None], 64).reshape(-1) if gate.bias is not None else None,
+                         2 * n, k, g, r)

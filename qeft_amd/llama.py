@@ -20,7 +20,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, fuse, qeft_cuda
 from .qlinear import QuantLinear
 from .quant import fake_quantize, minmax_params
 
@@ -210,6 +210,26 @@ def _add_rmsnorm(x, add, gamma, eps):
     return h, y
 
 
+def _prefill_operands(model):
+    """Per layer: q|k|v as one GEMM operand and gate|up interleaved in blocks of 64 rows (fuse.py), derived from the 4-bit
+    modules on the first prompt and kept on the model (a second copy of those weights, as the decode engine keeps its own;
+    `model._prefill_ops = None` drops them, e.g. after fine-tuned outlier weights were loaded)."""
+    ops = getattr(model, "_prefill_ops", None)
+    if ops is None:
+        ops = []
+        for L in model.model.layers:
+            at, mlp, o = L.self_attn, L.mlp, {}
+            qkv, gu = [at.q_proj, at.k_proj, at.v_proj], [mlp.gate_proj, mlp.up_proj]
+            plain = lambda ls: all(getattr(l, "bits", 4) == 4 and not l.training and getattr(l, "fused", True) for l in ls)   # noqa: E731
+            if plain(qkv) and all(l.outfeatures % 128 == 0 for l in qkv):
+                o["qkv"] = fuse.concat_gemm_operand(qkv)
+            if plain(gu) and mlp.gate_proj.outfeatures % 64 == 0:
+                o["gu"] = fuse.pair64_gemm_operand(*gu)
+            ops.append(o)
+        model._prefill_ops = ops
+    return ops
+
+
 @torch.no_grad()
 def prefill(model: "QuantLlama", tokens, engine=None):
     """Batched forward over T prompt tokens through the packed QuantLinears: T >= 8 rows take the MFMA GEMM path
@@ -226,14 +246,16 @@ def prefill(model: "QuantLlama", tokens, engine=None):
     cos_t, sin_t = model.rope_cos[:T].contiguous(), model.rope_sin[:T].contiguous()
     lib = _lib.lib()
 
-    def rope(x):                                                      # [T, H, 128] fp16 -> rotated fp16 (fp32 math), in place
-        if x.is_cuda and x.is_contiguous():
-            _lib.check(lib.qeft_rope_rows(x.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), T, x.shape[1],
-                                          torch.cuda.current_stream(x.device).cuda_stream))
+    def rope(x, heads=None):                                          # [T, H, 128] fp16 -> rotated fp16 (fp32 math), in place
+        if x.is_cuda and x.stride(-1) == 1 and x.stride(1) == 128:     # rows may be wider than their heads (fused q|k|v)
+            _lib.check(lib.qeft_rope_rows(x.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), T, heads or x.shape[1],
+                                          x.stride(0), torch.cuda.current_stream(x.device).cuda_stream))
             return x
         a, b = x[..., :64].float(), x[..., 64:].float()
         return torch.cat([a * cos - b * sin, b * cos + a * sin], dim=-1).half()
 
+    fused = _prefill_operands(model) if T >= 8 and h.is_cuda else None
+    hq, hkv = s.n_heads * 128, s.n_kv_heads * 128
     delta = None                                                      # the previous layer's down_proj output, added by the next norm
     for li, L in enumerate(model.model.layers):
         at, mlp = L.self_attn, L.mlp
@@ -241,9 +263,18 @@ def prefill(model: "QuantLlama", tokens, engine=None):
             x = _rmsnorm(h, L.input_layernorm, s.rms_eps)
         else:
             h, x = _add_rmsnorm(h, delta, L.input_layernorm, s.rms_eps)
-        q = rope(at.q_proj(x).view(T, s.n_heads, 128))
-        k = rope(at.k_proj(x).view(T, s.n_kv_heads, 128))
-        v = at.v_proj(x).view(T, s.n_kv_heads, 128)
+        fo = fused[li] if fused is not None else {}
+        if "qkv" in fo:
+            # q|k|v as one GEMM (N = 3 x 4096: 768 tiles of 256 x 128 = three whole rounds of the chip); q, k, v are views of
+            # its output, rotary over the q and k heads of every row in one launch
+            op = fo["qkv"]
+            y = qeft_cuda.gemm_4bit_qeft(x, op.qweight, op.scales, op.scaled_zeros, op.oweight, op.bias)
+            rope(y.view(T, s.n_heads + 2 * s.n_kv_heads, 128), s.n_heads + s.n_kv_heads)
+            q, k, v = (y[:, a:b].view(T, -1, 128) for a, b in ((0, hq), (hq, hq + hkv), (hq + hkv, hq + 2 * hkv)))
+        else:
+            q = rope(at.q_proj(x).view(T, s.n_heads, 128))
+            k = rope(at.k_proj(x).view(T, s.n_kv_heads, 128))
+            v = at.v_proj(x).view(T, s.n_kv_heads, 128)
         if engine is not None:
             engine.kc[li][:, :T] = k.transpose(0, 1)
             engine.vc[li][:, :T] = v.transpose(0, 1)
@@ -255,7 +286,11 @@ def prefill(model: "QuantLlama", tokens, engine=None):
                                                              vv.transpose(0, 1)[None], is_causal=True)[0]    # [H, T, 128]
         a = a.transpose(0, 1).reshape(T, s.hidden).contiguous()
         h, x = _add_rmsnorm(h, at.o_proj(a), L.post_attention_layernorm, s.rms_eps)     # o_proj gathers its own column order
-        delta = mlp.down_proj(mlp.up_proj.forward_silu_mul(x, mlp.gate_proj(x)))     # SiLU(gate) * up in the up_proj GEMM's epilogue
+        if "gu" in fo and qeft_cuda.gemm_gateup_supported(T, fo["gu"]):
+            act = qeft_cuda.gemm_4bit_gateup(x, fo["gu"])             # gate|up as one GEMM, SiLU(gate) * up its epilogue
+        else:
+            act = mlp.up_proj.forward_silu_mul(x, mlp.gate_proj(x))   # SiLU(gate) * up in the up_proj GEMM's epilogue
+        delta = mlp.down_proj(act)
     if engine is not None:
         engine.set_position(T)
     _, hn = _add_rmsnorm(h, delta, model.model.norm, s.rms_eps)

@@ -109,6 +109,29 @@ def gemm_4bit_qeft(in_feats, kernel, scales, zeros, oweights, bias=None):
     return out
 
 
+def gemm_gateup_supported(m, op):
+    """Whether gemm_4bit_gateup takes `m` rows of the fuse.pair64_gemm_operand `op`."""
+    return bool(_lib.lib().qeft_gemm_w4_gateup_supported(m, op.outfeatures, op.infeatures, op.group_size, op.outlierfeatures))
+
+
+def gemm_4bit_gateup(in_feats, op):
+    """silu(gate_proj(x)) * up_proj(x) from ONE launch: `op` = fuse.pair64_gemm_operand(gate_proj, up_proj).  Extension."""
+    x = in_feats.contiguous()
+    k = x.shape[-1]
+    _need(x.dtype == torch.float16 and k == op.infeatures, "in_feats must be Half [..., K] of the operand's K")
+    m = x.numel() // k
+    out = torch.empty(*in_feats.shape[:-1], op.outfeatures // 2, dtype=in_feats.dtype, device=in_feats.device)
+    if m == 0:
+        return out
+    with torch.cuda.device(in_feats.device):
+        _lib.check(_lib.lib().qeft_gemm_w4_gateup(x.data_ptr(), op.qweight.data_ptr(), op.scales.data_ptr(),
+                                                  op.scaled_zeros.data_ptr(),
+                                                  op.oweight.data_ptr() if op.oweight is not None else None,
+                                                  op.bias.data_ptr() if op.bias is not None else None, out.data_ptr(), m,
+                                                  op.outfeatures, k, op.group_size, op.outlierfeatures, _stream(x)))
+    return out
+
+
 _GEMM_WS = {}   # (device index, stream) -> fp32 scratch of the split-K GEMM
 
 

@@ -139,7 +139,8 @@ def test_round2_entries_reject_bad_arguments_without_a_gpu():
     assert lib.qeft_decode_linear_hnorm(ok_ptr, ok_ptr, ok_ptr, ok_ptr, ok_ptr, None, ok_ptr, 4096, 4100, 128, 128, 0, 1e-5, None) != 0
     assert lib.qeft_lm_head_f16(ok_ptr, ok_ptr, ok_ptr, ok_ptr, 4000, 32000, 1e-5, None) != 0      # hidden not a multiple of 512
     assert lib.qeft_lm_head_f16(ok_ptr, ok_ptr, None, ok_ptr, 4096, 32000, 1e-5, None) != 0
-    assert lib.qeft_rope_rows(None, ok_ptr, ok_ptr, 4, 2, None) != 0
-    assert lib.qeft_rope_rows(ok_ptr, ok_ptr, ok_ptr, 0, 2, None) != 0
+    assert lib.qeft_rope_rows(None, ok_ptr, ok_ptr, 4, 2, 256, None) != 0
+    assert lib.qeft_rope_rows(ok_ptr, ok_ptr, ok_ptr, 0, 2, 256, None) != 0
+    assert lib.qeft_rope_rows(ok_ptr, ok_ptr, ok_ptr, 4, 2, 128, None) != 0      # rows narrower than their heads
     assert lib.qeft_decode_linear_blocks(4096) == 256 and lib.qeft_decode_linear_blocks(22016) == 459
     assert lib.qeft_decode_linear_blocks(5120) == 160          # between 256 and 512 row sets: two per block

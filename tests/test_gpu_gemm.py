@@ -146,6 +146,37 @@ def test_gemm_silu_mul_epilogue(m, n, k, r, fused):
     assert rel_err(y.cpu().numpy(), g64 / (1 + np.exp(-g64)) * ref) < REL_TOL
 
 
+@pytest.mark.parametrize("m,n,k,r", [(2048, 1792, 512, 128), (300, 256, 384, 0), (1030, 3520, 448, 64), (8, 64, 384, 128)])
+def test_gemm_gateup_one_launch(m, n, k, r):
+    """gate_proj and up_proj as one GEMM over the 64-row-interleaved operand with SiLU(gate) * up as its epilogue == the two
+    GEMMs followed by qeft_silu_mul: bit for bit where those take the same kernel, within fp16 rounding where the separate
+    launches fall to another tier; at any row count the entry says it supports."""
+    import types
+    from qeft_amd import _lib, fuse, qeft_cuda
+    g = 128 if k % 128 == 0 else 64
+    ls = []
+    for seed in (1, 2):
+        b = O.make_layer(n, k, r, g, seed=seed + n, bias=True)
+        t = layer_to_torch(b, DEV)
+        ls.append(types.SimpleNamespace(qweight=t["qweight"], scales=t["scales"], scaled_zeros=t["scaled_zeros"], oweight=t.get("oweight"),
+                                        bias=t["bias"], outfeatures=n, infeatures=k, group_size=g, outlierfeatures=r, bits=4))
+    op = fuse.pair64_gemm_operand(*ls)
+    x = torch.from_numpy(O.make_activation(m, k, r, seed=m)).to(DEV)
+    assert qeft_cuda.gemm_gateup_supported(m, op)
+    y = qeft_cuda.gemm_4bit_gateup(x, op)
+    assert _lib.last_variant() == "gemm_v3_256x128+silu_pair"
+    gate, up = (qeft_cuda.gemm_4bit_qeft(x, l.qweight, l.scales, l.scaled_zeros, l.oweight if r else None, l.bias) for l in ls)
+    same_kernel = _lib.last_variant() == "gemm_v3_256x128"        # smaller problems: another tier, another summation order
+    two = torch.empty_like(up)
+    _lib.check(_lib.lib().qeft_silu_mul(gate.data_ptr(), up.data_ptr(), two.data_ptr(), up.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert y.shape == (m, n)
+    if same_kernel:
+        assert torch.equal(y, two)
+    else:
+        assert rel_err(y.cpu().numpy(), two.float().cpu().numpy()) < 2e-3
+
+
 def test_pack_oweight_device_bit_exact():
     from qeft_amd import qeft_cuda
     ow = (np.random.default_rng(0).standard_normal((64, 128))).astype(np.float16)

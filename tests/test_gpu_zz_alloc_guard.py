@@ -127,7 +127,7 @@ lo = torch.empty(7, dtype=torch.float16, device=DEV)
 _lib.check(lib.qeft_lm_head_f16(hh.data_ptr(), gg.data_ptr(), ww.data_ptr(), lo.data_ptr(), 512, 7, 1e-5, st))
 rr = torch.randn(3, 1, 128, device=DEV).half(); cc = torch.randn(3, 64, device=DEV); ss = torch.randn(3, 64, device=DEV)
 want = torch.cat([rr[..., :64].float() * cc[:, None] - rr[..., 64:].float() * ss[:, None], rr[..., 64:].float() * cc[:, None] + rr[..., :64].float() * ss[:, None]], -1).half()
-_lib.check(lib.qeft_rope_rows(rr.data_ptr(), cc.data_ptr(), ss.data_ptr(), 3, 1, st))
+_lib.check(lib.qeft_rope_rows(rr.data_ptr(), cc.data_ptr(), ss.data_ptr(), 3, 1, 128, st))
 torch.cuda.synchronize()
 hn = (hh * torch.rsqrt((hh ** 2).mean() + 1e-5)).half()
 assert (lo.float() - hn.float() @ ww.float().t()).abs().max().item() < 2e-2 and torch.equal(rr, want)

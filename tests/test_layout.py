@@ -81,3 +81,37 @@ def test_set_kernel_binds_forward_like_reference():
     q2.set_for_wct()
     assert isinstance(q2.oweight, torch.nn.Parameter) and q2.oweight.dtype == torch.float32 and q2.oweight.requires_grad
     assert isinstance(q2.qweight, torch.nn.Parameter) and not q2.qweight.requires_grad
+
+
+def _ns(bufs, n, k, r, g):
+    import types
+    import torch
+    t = {a: torch.from_numpy(np.ascontiguousarray(v)) for a, v in bufs.items() if a != "fake_weight"}
+    return types.SimpleNamespace(qweight=t["qweight"], scales=t["scales"], scaled_zeros=t["scaled_zeros"], oweight=t.get("oweight"),
+                                 bias=t.get("bias"), outfeatures=n, infeatures=k, group_size=g, outlierfeatures=r, bits=4)
+
+
+@pytest.mark.parametrize("n,k,r,g,bias", [(128, 256, 64, 64, True), (192, 384, 128, 128, False), (64, 128, 0, 128, True)])
+def test_gemm_side_fused_operands_are_row_permutations(n, k, r, g, bias):
+    """fuse.concat_gemm_operand / pair64_gemm_operand (prefill: q|k|v and gate|up as one GEMM each): dequantising the derived
+    buffers with the oracle gives exactly the source layers' dense weights, rows concatenated / interleaved in blocks of 64."""
+    from oracle import qeft_oracle as O
+    from qeft_amd import fuse
+    a, b = O.make_layer(n, k, r, g, seed=1, bias=bias), O.make_layer(n, k, r, g, seed=2, bias=bias)
+    la, lb = _ns(a, n, k, r, g), _ns(b, n, k, r, g)
+    dense = lambda x: O.dequant_dense(x["qweight"], x["scales"], x["scaled_zeros"], x.get("oweight") if r else None, g)   # noqa: E731
+    wa, wb = dense(a), dense(b)
+
+    def dense_op(op):
+        return O.dequant_dense(op.qweight.numpy(), op.scales.numpy(), op.scaled_zeros.numpy(),
+                               op.oweight.numpy() if op.oweight is not None else None, g)
+    cat = fuse.concat_gemm_operand([la, lb])
+    assert cat.outfeatures == 2 * n
+    assert np.array_equal(dense_op(cat), np.concatenate([wa, wb], 0))
+    p64 = fuse.pair64_gemm_operand(la, lb)
+    want = np.stack([wa.reshape(n // 64, 64, k), wb.reshape(n // 64, 64, k)], 1).reshape(2 * n, k)
+    assert p64.outfeatures == 2 * n
+    assert np.array_equal(dense_op(p64), want)
+    if bias:
+        assert np.array_equal(cat.bias.numpy(), np.concatenate([a["bias"], b["bias"]]))
+        assert np.array_equal(p64.bias.numpy(), np.stack([a["bias"].reshape(-1, 64), b["bias"].reshape(-1, 64)], 1).reshape(-1))

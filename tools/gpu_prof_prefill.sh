@@ -13,7 +13,7 @@ import csv, collections
 rows = list(csv.DictReader(open('gpurun_out/prof_prefill/run_kernel_trace.csv')))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 g = [i for i, r in enumerate(rows) if 'gemm_w4_kernel_v3' in r['Kernel_Name']]
-sel = rows[g[-224] - 3:]                      # the last pass: its 224 GEMM launches and what lies between them
+sel = rows[g[-(len(g) // 4)] - 3:]            # the last of the four passes: its GEMM launches and what lies between them
 t0 = int(sel[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in sel)
 acc = collections.defaultdict(lambda: [0, 0])
 for r in sel:
