@@ -12,7 +12,7 @@ from qeft_amd import qeft_cuda, _lib
 DEV = "cuda:0"
 CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 LARGE = len(sys.argv) > 2 and sys.argv[2] == "large"       # shapes that reach the MFMA GEMV and the 128- / 256-row GEMM tiers
-rng = np.random.default_rng(20261004)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "20261004")))
 fails, t0, seen = [], time.time(), {}
 if len(sys.argv) > 2 and sys.argv[2] == "v3":
     # the engine's decode GEMV (qeft_decode_linear) on random shapes of its own domain: N % 16, K % 128, group 128, r in {0, 128}
