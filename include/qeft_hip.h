@@ -49,7 +49,15 @@ int qeft_last_hip_error(void);
  * diagnostic only (the parity tests assert it so that every routing tier keeps its coverage). */
 const char* qeft_last_variant(void);
 
-/* Decode GEMV, m in 1..7, no outlier slice.
+/* Kernel reached by the three gemv entries below (qeft_last_variant() names it):
+ *   "gemv_v3" (m = 1) / "gemv_v3_mb" (m = 2..7): the round-2 MFMA GEMV of csrc/gemv_v3.h, taken when n % 16 == 0, k % 128 == 0,
+ *       group_size in {128, k}, n_out in {0, 128}, no fp16 `residual`, operands 16-byte aligned.  It consumes the operands as the
+ *       checkpoint holds them: scales / scaled_zeros [k/g][n] (or the sz_packed shadow when given), oweight_interleaved,
+ *       reorder_ids gathered inside the launch.  Batches whose x rows exceed the block's LDS run as several launches.
+ *   "gemv_mfma" / "gemv_valu": the round-1 kernels, for every other accepted shape (group sizes 32 / 64 / 256, n_out 32 / 64 /
+ *       96, n % 16 != 0, k % 128 != 0, a residual).  QEFT_GEMV_V3=0 in the environment forces them everywhere.
+ *
+ * Decode GEMV, m in 1..7, no outlier slice.
  * Replaces gemv_4bit(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size)
  * (qeft/kernel/quantization_new/gemv/gemv_cuda.cu:358-525). */
 int qeft_gemv_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
@@ -235,6 +243,10 @@ int qeft_decode_linear_hnorm(const void* h32, const void* gamma_x, const void* q
                              const void* bias, void* y, int n, int k, int group_size, int n_out, int mode, float eps,
                              qeft_stream_t stream);
 long long qeft_gemv_v3_check_extents(int n, int k, int group_size, int n_out, int n_ssq_in, int shrink_rows);
+/* The same self-check for the launches the reference's gemv entries make on the CHECKPOINT-layout operands (qeft_gemv_w4,
+ * qeft_gemv_w4_qeft, qeft_gemv_w4_fused): scales / scaled_zeros fp16 [k/g][n] staged raw, oweight_interleaved, m = 1..7 batch
+ * rows, optional reorder_ids gather; also checks every LDS destination of the staging against the block's LDS carve-up. */
+long long qeft_gemv_v3_check_extents_ckpt(int n, int k, int group_size, int n_out, int m, int gather, int shrink_rows);
 
 /* Producer-form helpers for the same scheme.
  * qeft_token_begin_norm: qeft_token_begin + h32 = float(embed[*tok]), h_norm = fp16(embed[*tok] * gamma),

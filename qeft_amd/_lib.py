@@ -54,6 +54,7 @@ SIGNATURES = {
     "qeft_decode_linear": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, ctypes.c_float, _p, _p, _p, _p],
     "qeft_decode_linear_w3": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, ctypes.c_float, _p, _p, _p, _p],
     "qeft_gemv_v3_check_extents": [_i, _i, _i, _i, _i, _i],
+    "qeft_gemv_v3_check_extents_ckpt": [_i, _i, _i, _i, _i, _i, _i],
     "qeft_decode_linear_hnorm": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, ctypes.c_float, _p],
     "qeft_token_begin_norm_blocks": [_i],
     "qeft_token_begin_norm": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
@@ -86,7 +87,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name in ("qeft_error_string", "qeft_last_variant") else
                           ctypes.c_longlong if name in ("qeft_gemm_w4_workspace_bytes", "qeft_gemm_w4_dx_workspace_bytes",
-                                                       "qeft_gemv_v3_check_extents") else _i)
+                                                       "qeft_gemv_v3_check_extents", "qeft_gemv_v3_check_extents_ckpt") else _i)
         _lib = l
     return _lib
 

@@ -1,6 +1,7 @@
 // extern "C" entry points declared in include/qeft_hip.h: argument validation + dispatch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <stdint.h>
 
@@ -10,6 +11,8 @@
 
 namespace qeft {
 hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st);
+int gemv_v3_max_rows(V3Args a, int m_want);
+long long gemv_v3_count_out_of_range_ckpt(const V3Geom& G, int n_rows_have, int m, bool gather);
 int gemv_v3_blocks(int nsets);
 bool gemv_v3_ok(int K, int G, int n_out);
 long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq_in, bool xn, int bits);
@@ -81,6 +84,12 @@ static int finish(hipError_t e) {
     return QEFT_ERR_LAUNCH;
 }
 
+// QEFT_GEMV_V3=0: the reference's gemv entries keep the round-1 kernels (A/B timing, and the parity tests of those kernels)
+static bool v3_route_enabled() {
+    static const int on = [] { const char* e = getenv("QEFT_GEMV_V3"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int check_common(int n, int k, int g, int n_out) {
@@ -120,6 +129,39 @@ static int gemv_fused_impl(const void* x, const void* qweight, const void* scale
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight_il))) return QEFT_ERR_ALIGN;
+    if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
+    if (bits == 4 && v3_route_enabled() && !residual && n % 16 == 0 && qeft::gemv_v3_ok(k, group_size, n_out) && aligned16(scales) &&
+        aligned16(scaled_zeros) && (!reorder_ids || aligned16(reorder_ids))) {
+        // The round-2 decode GEMV on the operands as the checkpoint holds them (gemv_v3.h): the scales staged raw and packed in
+        // LDS (or the sz_packed shadow when the caller has one), the outlier slab from oweight_interleaved, the o_proj gather
+        // inside the launch, m batch rows as D rows of the same MFMAs.  A batch whose x rows do not fit the block's LDS goes in
+        // several launches (as the round-1 kernel below does).
+        qeft::V3Args v{};
+        v.g.K = k;
+        v.g.n_out = n_out;
+        v.g.nsteps = k / 128;
+        v.g.nfull = (k - n_out) / 128;
+        v.g.ngroups = group_size == k ? 1 : k / 128;
+        v.g.nsets = n / 16;
+        v.qw = (const uint8_t*)qweight;
+        v.szp = (const uint8_t*)sz_packed;
+        v.scales = (const qeft::f16*)scales;
+        v.zeros = (const qeft::f16*)scaled_zeros;
+        v.ow_il = (const uint8_t*)oweight_il;
+        v.bias = (const qeft::f16*)bias;
+        v.ids = reorder_ids;
+        const int mmax = qeft::gemv_v3_max_rows(v, m);
+        if (mmax >= 1) {
+            const int nlaunch = (m + mmax - 1) / mmax, per = (m + nlaunch - 1) / nlaunch;      // 7 rows as 4 + 3, not 6 + 1
+            for (int m0 = 0; m0 < m; m0 += per) {
+                v.m = m - m0 < per ? m - m0 : per;
+                v.x = (const qeft::f16*)x + (size_t)m0 * k;
+                v.y = (qeft::f16*)y + (size_t)m0 * n;
+                if (const hipError_t e = qeft::gemv_v3_launch(v, qeft::V3_MODE_PLAIN, (hipStream_t)stream)) return finish(e);
+            }
+            return QEFT_OK;
+        }
+    }
     qeft::GemvArgs a;
     a.x = (const qeft::f16*)x;
     a.qw = (const uint8_t*)qweight;
@@ -141,7 +183,6 @@ static int gemv_fused_impl(const void* x, const void* qweight, const void* scale
     a.dbg2 = nullptr;
     a.ow_plain = nullptr;
     a.m_rt = 1;
-    if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
     if (group_size != k && (group_size & (group_size - 1)) != 0) return QEFT_ERR_GROUP;  // GEMV: power of two or == K
     a.gshift = (group_size == k) ? 31 : __builtin_ctz(group_size);
     if (bits == 3) {
@@ -615,6 +656,12 @@ long long qeft_gemv_v3_check_extents(int n, int k, int group_size, int n_out, in
     if (n_ssq_in < 0 || n_ssq_in > qeft::V3_MAX_SSQ) return -1;
     return qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in, n_ssq_in == 0, 4) +
            (G.nfull > 0 ? qeft::gemv_v3_count_out_of_range(G, n - shrink_rows, n_ssq_in, false, 3) : 0);
+}
+
+long long qeft_gemv_v3_check_extents_ckpt(int n, int k, int group_size, int n_out, int m, int gather, int shrink_rows) {
+    qeft::V3Geom G{};
+    if (v3_geom(G, n, k, group_size, n_out, qeft::V3_MODE_PLAIN) != QEFT_OK || m < 1 || m > qeft::V3_MAX_M) return -1;
+    return qeft::gemv_v3_count_out_of_range_ckpt(G, n - shrink_rows, m, gather != 0);
 }
 
 int qeft_token_begin_norm_blocks(int hidden) { return hidden >= 8 ? qeft::token_begin_norm_blocks(hidden) : 0; }

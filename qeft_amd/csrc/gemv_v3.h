@@ -42,6 +42,14 @@ constexpr int V3_MAX_RS = 4;    // 16-row sets per block (LDS is carved for rs_c
 constexpr int V3_MAX_SSQ = 512; // partial sums of squares a consumer accepts
 constexpr int V3_MODE_PLAIN = 0;
 constexpr int V3_MODE_PAIR = 1; // rows pair-interleaved: set g = gate rows [8g, 8g+8) then up rows [8g, 8g+8); y[8g + i] = silu(gate) * up
+constexpr int V3_MAX_M = 7;     // batch rows of one launch (the reference's gemv entries serve m = 1..7, gemv_cuda_qeft.cu:433-466)
+// run-time flags of a launch, packed beside nblk / rs_cap in one preloaded dword (V3_KERNEL_ARGS)
+constexpr uint32_t V3_F_PERCH = 1u << 24;   // one group per row (group size == K)
+constexpr uint32_t V3_F_XN = 1u << 25;      // x is fp32 h, xn_gamma its gamma: the whole RMSNorm in this launch
+constexpr uint32_t V3_F_SZN = 1u << 26;     // scales / scaled_zeros in their CHECKPOINT layout fp16 [K/g][N] (szp = scales, xn_gamma = zeros)
+constexpr uint32_t V3_F_OWIL = 1u << 27;    // outlier slice from oweight_interleaved [N/2][256] (pack_oweight, qlinear.py:70-79)
+constexpr uint32_t V3_F_GATHER = 1u << 31;  // x[:, ids] (qlinear.py:275), ids int32 [K] in the tail
+constexpr int V3_F_M_SHIFT = 28;            // bits 28..30: m - 1
 
 struct V3Geom {
     int K, n_out, nsteps, nfull, ngroups, nsets;   // nsets = N / 16
@@ -69,6 +77,13 @@ struct V3Args {
     float* ssq_out;
     long long* dbg;         // lab only (ABL & 8): per block 8 x 100 MHz time stamps of wave 0; never read in the product
     int bits;               // 4 (0 is taken as 4), or 3: qw is the 3-bit extension layout int32 [N/16][nfull * 192]
+    // ---- the reference's entry points (gemv_4bit[_qeft], QuantLinear.forward for < 8 rows): operands as the checkpoint holds them
+    const f16* scales;      // with `zeros`: fp16 [K/g][N] each, used when szp == NULL (staged raw, packed in LDS)
+    const f16* zeros;
+    const uint8_t* ow_il;   // oweight_interleaved fp16 [N/2][256], used when ow == NULL and n_out > 0
+    const int* ids;         // optional reorder_ids int32 [K]: the launch consumes x[:, ids]
+    int m;                  // batch rows 1..7 (0 is taken as 1); x is [m][K], y [m][N]; m > 1: PLAIN, no residual / ssq_in / xn
+    int nw;                 // waves per block chosen by the launcher (LDS sizing)
 };
 
 // What the kernel receives.  The first 16 dwords of the kernel-argument segment -- the four operand pointers and the
@@ -85,28 +100,61 @@ struct V3Tail {
     f16* ynorm;
     float* ssq_out;
     long long* dbg;
+    const int* ids;
     int n_out, nsteps, nsets, n_ssq_in;
     float eps;
 };
 inline V3Tail v3_tail(const V3Args& a) {
-    return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps};
+    return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.ids, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps};
+}
+inline uint32_t v3_flags(const V3Args& a) {
+    const int m = a.m > 0 ? a.m : 1;
+    return ((a).g.ngroups == 1 && (a).g.K > 128 ? V3_F_PERCH : 0u) | ((a).xn_gamma ? V3_F_XN : 0u) | (!a.szp ? V3_F_SZN : 0u) |
+           (!a.ow && a.g.n_out > 0 ? V3_F_OWIL : 0u) | (a.ids ? V3_F_GATHER : 0u) | ((uint32_t)(m - 1) << V3_F_M_SHIFT);
 }
 // 13 dwords (14 user SGPRs are available for preloading next to the kernarg pointer): five pointers, K, and two packed words:
 // nblk | rs_cap << 16 | per-channel << 24 | xn << 25 and sets_q | sets_r << 16 (nblk, sets_r < 65536: gemv_v3_launch checks);
 // the step and group counts follow from K and the flags
-#define V3_KERNEL_ARGS(a) (a).qw, (a).x, (a).szp, (a).ow, (a).xn_gamma, (a).g.K, \
-    (uint32_t)(a).nblk | ((uint32_t)(a).rs_cap << 16) | ((a).g.ngroups == 1 && (a).g.K > 128 ? 1u << 24 : 0u) | ((a).xn_gamma ? 1u << 25 : 0u), \
+// (checkpoint-layout launches: the scales pointer travels in the szp slot, scaled_zeros in the xn_gamma slot, oweight_interleaved in ow's)
+#define V3_KERNEL_ARGS(a) (a).qw, (a).x, ((a).szp ? (a).szp : (const uint8_t*)(a).scales), ((a).ow ? (a).ow : (a).ow_il), \
+    ((a).szp ? (a).xn_gamma : (a).zeros), (a).g.K, (uint32_t)(a).nblk | ((uint32_t)(a).rs_cap << 16) | qeft::v3_flags(a), \
     (uint32_t)(a).sets_q | ((uint32_t)(a).sets_r << 16), qeft::v3_tail(a)
 
 // ---- LDS carve-up (bytes); every DMA-filled region is a whole number of 1 KB pieces
 __host__ __device__ constexpr int v3_x_bytes(int K) { return (K * 2 + 1023) / 1024 * 1024; }
 __host__ __device__ constexpr int v3_sz_bytes(int ngroups) { return (ngroups * 64 + 1023) / 1024 * 1024; }   // per row set
 __host__ __device__ constexpr int v3_xf_bytes(int K) { return (K * 4 + 1023) / 1024 * 1024; }   // fp32 h of an xn launch
-__host__ __device__ constexpr size_t v3_red_bytes(int rs_cap) { return ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024; }
-__host__ __device__ constexpr size_t v3_smem_bytes(int K, int ngroups, int n_out, int rs_cap, bool xn = false) {
-    return (size_t)v3_x_bytes(K) + (size_t)rs_cap * v3_sz_bytes(ngroups) + (n_out > 0 ? (size_t)rs_cap * 4096 : 0) +
-           1024 /* epilogue operands */ + 2048 /* ssq_in */ + v3_red_bytes(rs_cap) +
-           (xn ? (size_t)v3_xf_bytes(K) + v3_x_bytes(K) : 0);      /* xn: fp32 h + its gamma, behind everything else */
+__host__ __device__ constexpr int v3_szraw_bytes(int ngroups) { return (ngroups * 32 + 1023) / 1024 * 1024; }   // per row set and array (checkpoint-layout scales)
+// batch rows of x sit XS bytes apart: whole pieces, plus 16 bytes when there are several rows so that the A-fragment reads of
+// different batch rows (same k) fall into different banks
+__host__ __device__ constexpr int v3_x_stride(int K, int m) { return v3_x_bytes(K) + (m > 1 ? 16 : 0); }
+// per-wave partial sums: m == 1: [rs_cap][NW_MAX][16] floats; m > 1: [rs_cap][nw][8 batch rows][16]
+__host__ __device__ constexpr size_t v3_red_bytes(int rs_cap, int m = 1, int nw = V3_NW_MAX) {
+    return m > 1 ? ((size_t)rs_cap * nw * 8 * 16 * 4 + 1023) / 1024 * 1024 : ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024;
+}
+struct V3Lds {              // byte offsets of the regions inside the block's dynamic LDS
+    uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, total;
+};
+__host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_cap, int m, int nw, bool xn, bool szn, bool gather) {
+    V3Lds L;
+    uint32_t o = 0;
+    L.xs = o;   o += ((uint32_t)m * v3_x_stride(K, m) + 1023u) / 1024u * 1024u;          // [m][K] fp16 as the MFMAs read it
+    L.szl = o;  o += (uint32_t)rs_cap * v3_sz_bytes(ngroups);                               // [rs_cap][groups][16] u32
+    L.owl = o;  o += n_out > 0 ? (uint32_t)rs_cap * 4096u : 0u;                             // [rs_cap] 4 KB outlier slab (swizzled)
+    L.epl = o;  o += 1024;                                                                  // epilogue operands
+    L.ssql = o; o += 2048;                                                                  // ssq_in
+    L.red = o;  o += (uint32_t)v3_red_bytes(rs_cap, m, nw);
+    L.xf = o;   o += xn ? (uint32_t)v3_xf_bytes(K) : 0u;                                    // xn: fp32 h
+    L.xg = o;   o += xn ? (uint32_t)v3_x_bytes(K) : 0u;                                     //     its gamma
+    L.szraw = o; o += szn ? 2u * rs_cap * v3_szraw_bytes(ngroups) : 0u;                     // [2 arrays][rs_cap][groups][16] fp16
+    L.idsl = o; o += gather ? (uint32_t)v3_xf_bytes(K) : 0u;                                // reorder_ids int32 [K]
+    L.xraw = o; o += gather ? (uint32_t)m * v3_x_bytes(K) : 0u;                             // x rows before the gather
+    L.total = o;
+    return L;
+}
+__host__ __device__ inline size_t v3_smem_bytes(int K, int ngroups, int n_out, int rs_cap, bool xn = false, int m = 1, int nw = V3_NW_MAX,
+                                                bool szn = false, bool gather = false) {
+    return v3_lds(K, ngroups, n_out, rs_cap, m, nw, xn, szn, gather).total;
 }
 
 // ---- source byte offsets of every load (relative to the operand's base)
@@ -140,6 +188,18 @@ __host__ __device__ inline size_t v3_ow_off(int g, int j, int lane) {
     const int row = 4 * j + (lane >> 4), cc = (lane & 15) ^ row;
     return ((size_t)(g * 16 + row) * 128 + cc * 8) * 2;
 }
+// outlier piece j of set g from oweight_interleaved [N/2][256] fp16: the set's 8 interleaved rows (512 B each), two per piece.
+// LDS position p (16-byte chunk 0..31 of interleaved row R) <- source chunk ((p >> 1) ^ R) << 1 | (p & 1): the 32-byte pairs a
+// lane reads per MFMA are XOR-swizzled by the row so that the 8 rows of a read fall into different banks
+__host__ __device__ inline size_t v3_owil_off(int g, int j, int lane) {
+    const int R = 2 * j + (lane >> 5), p = lane & 31, c = (((p >> 1) ^ R) << 1) | (p & 1);
+    return ((size_t)(g * 8 + R) * 256 + (size_t)c * 8) * 2;
+}
+// checkpoint-layout scales / scaled_zeros fp16 [ngroups][N]: piece j of set g = groups 32 j .. 32 j + 31, two lanes (8 rows each) per group
+__host__ __device__ inline size_t v3_szn_off(const V3Geom& G, int g, int j, int lane) {
+    const int grp = 32 * j + (lane >> 1), gc = grp < G.ngroups ? grp : G.ngroups - 1;
+    return ((size_t)gc * G.nsets * 16 + (size_t)g * 16 + (size_t)(lane & 1) * 8) * 2;
+}
 // epilogue operands, one piece: lanes [0, 4 RS) = residual (4 floats of the block's rows each), lanes [16, 16 + 2 RS) =
 // gamma_out (8 halves each); every other lane re-reads lane 0's / lane 16's vector.  Byte offset into the respective vector.
 __host__ __device__ inline size_t v3_epi_off(int set0, int RS, int lane) {
@@ -171,21 +231,48 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// In-kernel time stamps of the lab build (tools/gemv_v3_lab.hip, -DQEFT_LAB, ABL & 8); compiled out of the product
+#if defined(QEFT_LAB)
+#define V3_STAMP(i) do { if (ABL & 8) ts[i] = wall_clock64(); } while (0)
+#else
+#define V3_STAMP(i) do { } while (0)
+#endif
+
+// The value a lane accumulates per row set: batch row 0 only (MB == 1: D row 0 = register 0 of the lanes kc == 0), or the four
+// D rows 4 kc .. 4 kc + 3 of the lane (MB == 2: batch rows 0..6 live in the lanes kc < 2)
+template <int MB> struct V3Val { typedef float type; };
+template <> struct V3Val<2> { typedef f32x4 type; };
+template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_pick(const f32x4& v) {
+    if constexpr (MB == 1) return v[0]; else return v;
+}
+template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_zero() {
+    if constexpr (MB == 1) return 0.f; else return f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ float v3_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f32x4 v3_fma(const f32x4& a, float b, const f32x4& c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
+
 // NW waves per block (8, or 16 for launches of one block per CU: twice the instruction streams per SIMD for the same bytes);
 // wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
-template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4>
+// MB: 1 = one batch row (the decode engine, and m = 1 at the reference's entry points); 2 = up to V3_MAX_M batch rows.
+template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1>
 __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
     static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
     static_assert(BITS == 4 || BITS == 3, "4-bit checkpoint layout or the 3-bit extension layout (oracle: pack_w3)");
+    static_assert(MB == 1 || (MODE == V3_MODE_PLAIN && BITS == 4), "several batch rows: plain 4-bit launches only");
+    typedef typename V3Val<MB>::type val_t;
     // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
     // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
     // dependent scalar-memory round trip in the middle of the stream
-    const bool per_channel_f = (nblk_rscap_flags >> 24) & 1u, XN = (nblk_rscap_flags >> 25) & 1u;
-    V3Geom G{K_, a.n_out, a.nsteps, (K_ >> 7) - (OUTL ? 1 : 0), per_channel_f ? 1 : (K_ >> 7), a.nsets};
+    const bool per_channel_f = (nblk_rscap_flags & V3_F_PERCH) != 0, XN = MB == 1 && (nblk_rscap_flags & V3_F_XN) != 0;
+    const bool SZN = (nblk_rscap_flags & V3_F_SZN) != 0, OWIL = OUTL && (nblk_rscap_flags & V3_F_OWIL) != 0;
+    const bool GATHER = (nblk_rscap_flags & V3_F_GATHER) != 0;
+    const int m = MB == 1 ? 1 : (int)((nblk_rscap_flags >> V3_F_M_SHIFT) & 7u) + 1;
     const int nblk = (int)(nblk_rscap_flags & 0xffffu), rs_cap = (int)((nblk_rscap_flags >> 16) & 0xffu);
     const int sets_q = (int)(setsq_setsr & 0xffffu), sets_r = (int)(setsq_setsr >> 16);
+    // (nsets from the preloaded words: the checkpoint-layout scale pieces need N before the tail has arrived)
+    V3Geom G{K_, a.n_out, a.nsteps, (K_ >> 7) - (OUTL ? 1 : 0), per_channel_f ? 1 : (K_ >> 7), sets_q * nblk + sets_r};
     const int ssq_n = a.n_ssq_in;
     const float eps = a.eps;
     const f16* const bias = a.bias;
@@ -197,19 +284,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     const uint8_t* const ssq_in = (const uint8_t*)a.ssq_in;
     const uint8_t* const residual = (const uint8_t*)a.residual;
     const uint8_t* const gamma_out = (const uint8_t*)a.gamma_out;
+    const uint8_t* const idsp = (const uint8_t*)a.ids;
     asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(rs_cap), "s"(nblk), "s"(sets_q), "s"(sets_r), "s"(xptr), "s"(qw),
                  "s"(szp), "s"(ow), "s"(xn_gamma));
 
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
-    const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups);
-    uint8_t* xs = smem;                                               // [K] fp16 raw (+ padding to 1 KB)
-    uint8_t* szl = xs + XB;                                           // [rs_cap][SZB / 64][16] u32
-    uint8_t* owl = szl + rs_cap * SZB;                                // [rs_cap][16 rows][16 chunks ^ row][8] fp16
-    uint8_t* epl = owl + (OUTL ? rs_cap * 4096 : 0);                  // [64 lanes][16 B]: residual | gamma_out of the block's rows
-    float* ssql = (float*)(epl + 1024);                               // [512] ssq_in
-    float* red = ssql + V3_MAX_SSQ;                                   // [rs_cap][NW][16]
-    uint8_t* xf = (uint8_t*)red + v3_red_bytes(rs_cap);               // xn launches: [K] fp32 h, then its gamma [K] fp16
-    uint8_t* xg = xf + v3_xf_bytes(G.K);
+    const V3Lds L = v3_lds(G.K, G.ngroups, OUTL ? 128 : 0, rs_cap, m, NW, XN, SZN, GATHER);
+    const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups), XS = v3_x_stride(G.K, m);
+    uint8_t* const xs = smem + L.xs;                                  // [m][K] fp16 raw (rows XS apart)
+    uint8_t* const szl = smem + L.szl;                                // [rs_cap][SZB / 64][16] u32
+    uint8_t* const owl = smem + L.owl;                                // [rs_cap] 4 KB: 16 plain rows (chunks ^ row) or 8 interleaved rows
+    uint8_t* const epl = smem + L.epl;                                // [64 lanes][16 B]: residual | gamma_out of the block's rows
+    float* const ssql = (float*)(smem + L.ssql);                      // [512] ssq_in
+    float* const red = (float*)(smem + L.red);                        // [rs_cap][NW][16], or [rs_cap][NW][8][16] (MB == 2)
+    uint8_t* const xf = smem + L.xf;                                  // xn launches: [K] fp32 h, then its gamma [K] fp16
+    uint8_t* const xg = smem + L.xg;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -217,16 +306,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     const int nl = lane & 15, kc = lane >> 4;
     int set0, RS;
     v3_block_sets(v3_xcd_block(blockIdx.x, nblk), sets_q, sets_r, set0, RS);
+#if defined(QEFT_LAB)
     long long ts[7] = {0, 0, 0, 0, 0, 0, 0};    // ABL & 8: entry, ring issued, staging landed (barrier), steps done, (end), all waves done (barrier), values ready
-    if (ABL & 8) ts[0] = wall_clock64();
+#endif
+    V3_STAMP(0);
 
     // ---- 1. staging by LDS-DMA.  x: the waves take pieces w, w + NW, ..; per row set the scale words (piece j = wave) and
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
     //         wait for until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
     const int PX = XB >> 10, SPS = SZB >> 10;
     if (!XN) {
-        for (int p = wave; p < PX; p += NW)
-            v3_dma16(xptr + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(lds0 + ((uint32_t)p << 10)));
+        // (a gathering launch stages the rows as they are into xraw; step 3b writes xs)
+        const uint32_t xdst = lds0 + (GATHER ? L.xraw : L.xs), xstr = GATHER ? (uint32_t)XB : (uint32_t)XS;
+        for (int i = 0; i < m; ++i)
+            for (int p = wave; p < PX; p += NW)
+                v3_dma16(xptr + (size_t)i * G.K * 2 + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(xdst + (uint32_t)i * xstr + ((uint32_t)p << 10)));
     } else {               // fp32 h (2 PX pieces) and its gamma (PX pieces) go to their own regions; xs is written in step 3b
         const int PF = v3_xf_bytes(G.K) >> 10;
         for (int p = wave; p < PF + PX; p += NW) {
@@ -237,12 +331,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                          __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xg + ((uint32_t)(p - PF) << 10)));
         }
     }
+    const int SRB = v3_szraw_bytes(G.ngroups), SPR = SRB >> 10;
     for (int rs = 0; rs < RS; ++rs) {
-        for (int j = wave; j < SPS; j += NW)
-            v3_dma16(szp + v3_sz_off(G, set0 + rs, j, lane),
-                     __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)XB + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
+        if (!SZN) {
+            for (int j = wave; j < SPS; j += NW)
+                v3_dma16(szp + v3_sz_off(G, set0 + rs, j, lane),
+                         __builtin_amdgcn_readfirstlane(lds0 + L.szl + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
+        } else {            // checkpoint layout: scales (array 0, the szp slot) and scaled_zeros (array 1, the xn_gamma slot), packed in step 3b
+            for (int t = wave; t < 2 * SPR; t += NW) {
+                const int arr = t >= SPR ? 1 : 0, j = t - arr * SPR;
+                v3_dma16((arr ? (const uint8_t*)xn_gamma : szp) + v3_szn_off(G, set0 + rs, j, lane),
+                         __builtin_amdgcn_readfirstlane(lds0 + L.szraw + (uint32_t)(arr * rs_cap + rs) * SRB + ((uint32_t)j << 10)));
+            }
+        }
         if (OUTL && wave >= NW - 4)
-            v3_dma16(ow + v3_ow_off(set0 + rs, wave - (NW - 4), lane),
+            v3_dma16(ow + (OWIL ? v3_owil_off(set0 + rs, wave - (NW - 4), lane) : v3_ow_off(set0 + rs, wave - (NW - 4), lane)),
                      __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - (NW - 4)) << 10)));
     }
 
@@ -275,26 +378,35 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     }
 
     asm volatile("" ::"s"(G.nsteps), "s"(ssq_n), "s"(ssq_in), "s"(residual), "s"(gamma_out), "s"(eps), "s"(bias), "s"(yout), "s"(y32),
-                 "s"(ynorm), "s"(ssq_out));
-    if (ABL & 8) ts[1] = wall_clock64();
+                 "s"(ynorm), "s"(ssq_out), "s"(idsp));
+    V3_STAMP(1);
+    // ---- 1b. a gathering launch: reorder_ids (tail operand, so behind the ring) -> LDS, K * 4 bytes
+    if (GATHER) {
+        const int PI = v3_xf_bytes(G.K) >> 10;
+        for (int p = wave; p < PI; p += NW)
+            v3_dma16(idsp + v3_xf_off(G, p, lane), __builtin_amdgcn_readfirstlane(lds0 + L.idsl + ((uint32_t)p << 10)));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // ---- 3. staged data complete: this wave's pieces are older than its D ring loads
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
     // ---- 2b. epilogue-only operands, requested BEHIND the ring (they must not delay the weight stream): wave 1 the
     //          residual / gamma_out values of the block's rows, waves 2 and 3 the producer's partial sums of squares.  They
     //          complete before the vmcnt(0) every wave executes in front of the final barrier.
-    if (MODE == V3_MODE_PLAIN && residual && wave == 1) {
+    if (MB == 1 && MODE == V3_MODE_PLAIN && residual && wave == 1) {
         const bool g_lane = lane >= 16 && gamma_out != nullptr;
         v3_dma16((g_lane ? gamma_out : residual) + v3_epi_off(set0, RS, g_lane ? lane : (lane < 16 ? lane : 0)),
                  __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)epl));
     }
-    if (ssq_in && (wave == 2 || wave == 3) && (wave - 2) * 256 < ssq_n) {       // <= 2 pieces of 256 floats
+    if (MB == 1 && ssq_in && (wave == 2 || wave == 3) && (wave - 2) * 256 < ssq_n) {       // <= 2 pieces of 256 floats
         const int v = min((wave - 2) * 64 + lane, (ssq_n - 1) >> 2);             // clamped 16-byte vector of the array
         v3_dma16(ssq_in + (size_t)v * 16, __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ssql + (uint32_t)(wave - 2) * 1024u));
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // ---- 3b. xn launches: xs = fp16(h * gamma) (the producers' rounding, qeft_residual_norm), sum of h^2 per wave -> LDS.
-    //          This runs while the first weight loads are still on their way.
+    // ---- 3b. LDS -> LDS transforms of the staged data, while the first weight loads are still on their way:
+    //          xn:      xs = fp16(h * gamma) (the producers' rounding, qeft_residual_norm), sum of h^2 per wave -> LDS
+    //          gather:  xs[i][k] = xraw[i][ids[k]]  (QuantLinear.forward_outlier_out_proj's index_select, qlinear.py:275)
+    //          szn:     szl[rs][group][row] = scale | scaled_zero << 16 from the two checkpoint-layout images
     float xn_ss = 0.f;
     if (XN) {
         for (int e = tid * 4; e < G.K; e += NW * 64 * 4) {
@@ -310,16 +422,44 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         }
         xn_ss = wave_sum(xn_ss);
         if (lane == 0) ssql[wave] = xn_ss;             // the ssq_in region is free in an xn launch
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: __syncthreads() would drain the ring
     }
-    if (ABL & 8) ts[2] = wall_clock64();
+    if (GATHER) {
+        const uint8_t* const idsl = smem + L.idsl;
+        const uint8_t* const xraw = smem + L.xraw;
+        for (int e = tid * 4; e < G.K; e += NW * 64 * 4) {
+            const u32x4 id4 = *(const u32x4*)(idsl + (size_t)e * 4);
+            for (int i = 0; i < m; ++i) {
+                const uint8_t* row = xraw + (size_t)i * XB;
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = *(const uint16_t*)(row + (size_t)min(id4[j], (uint32_t)G.K - 1u) * 2);
+                *(u32x2*)(xs + (size_t)i * XS + (size_t)e * 2) = u32x2{v[0] | (v[1] << 16), v[2] | (v[3] << 16)};
+            }
+        }
+    }
+    if (SZN) {
+        const uint8_t* const sraw = smem + L.szraw;
+        const uint8_t* const zraw = sraw + (size_t)rs_cap * SRB;
+        for (int rs = 0; rs < RS; ++rs)
+            for (int q = tid; q < G.ngroups * 4; q += NW * 64) {     // q = (group, 4 rows)
+                const u32x2 sv = *(const u32x2*)(sraw + (size_t)rs * SRB + (size_t)q * 8);
+                const u32x2 zv = *(const u32x2*)(zraw + (size_t)rs * SRB + (size_t)q * 8);
+                *(u32x4*)(szl + (size_t)rs * SZB + (size_t)q * 16) =
+                    u32x4{(sv[0] & 0xffffu) | (zv[0] << 16), (sv[0] >> 16) | (zv[0] & 0xffff0000u),
+                          (sv[1] & 0xffffu) | (zv[1] << 16), (sv[1] >> 16) | (zv[1] & 0xffff0000u)};
+            }
+    }
+    if (XN || GATHER || SZN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: __syncthreads() would drain the ring
+    V3_STAMP(2);
 
-    // ---- 4. steps.  acc[rs]: lanes kc == 0 hold row nl of row set rs (batch row 0 = D row 0, register 0)
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    // ---- 4. steps.  acc[rs]: lanes kc == 0 hold row nl of row set rs (batch row 0 = D row 0, register 0); MB == 2: every lane
+    //         holds the batch rows 4 kc .. 4 kc + 3 (D rows) of row nl
+    val_t acc0 = v3_zero<MB>(), acc1 = v3_zero<MB>(), acc2 = v3_zero<MB>(), acc3 = v3_zero<MB>();
     uint32_t MAGIC = 0x64006400u, NEG1024 = 0xE400E400u;
     asm volatile("" : "+v"(MAGIC), "+v"(NEG1024));
     const v3h8 c8 = __builtin_bit_cast(v3h8, u32x4{NEG1024, NEG1024, NEG1024, NEG1024});
-    const uint8_t* xa = xs + kc * 64;      // this lane's 32-k chunk of a step: four 16-byte slots
+    // this lane's 32-k chunk of a step: four 16-byte slots; A row = lane & 15 = batch row (rows >= m re-read row m - 1)
+    const uint8_t* xa = xs + kc * 64 + (MB == 1 ? 0 : (size_t)min(nl, m - 1) * XS);
     const bool per_channel = G.ngroups == 1;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -330,24 +470,43 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         v3h8 xo[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) xo[jj] = px[jj];
+        // interleaved slab: lane (row nl, chunk kc) finds its row in interleaved row R = (nl / 8) * 4 + nl % 4, as the even
+        // (nl % 8 < 4) or odd halves of every dword; MFMA jj needs the 32 bytes of pair q = 4 kc + jj, stored at pair q ^ R
+        const int R = ((nl >> 3) << 2) | (nl & 3);
+        const uint32_t sel = (nl & 4) ? 0x07060302u : 0x05040100u;
         for (int rs = 0; rs < RS; ++rs) {
-            const uint8_t* prow = owl + rs * 4096 + nl * 256;
             f32x4 P = z4;
+            if (!OWIL) {
+                const uint8_t* prow = owl + rs * 4096 + nl * 256;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                P = __builtin_amdgcn_mfma_f32_16x16x32_f16(xo[jj], *(const v3h8*)(prow + (((kc * 4 + jj) ^ nl) & 15) * 16), P, 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj)
+                    P = __builtin_amdgcn_mfma_f32_16x16x32_f16(xo[jj], *(const v3h8*)(prow + (((kc * 4 + jj) ^ nl) & 15) * 16), P, 0, 0, 0);
+            } else {
+                const uint8_t* prow = owl + rs * 4096 + R * 512;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint8_t* pp = prow + (((kc * 4 + jj) ^ R) & 15) * 32;
+                    // (the two halves in the order kc & 1, !(kc & 1): the lanes of a 16-byte read group then cover all banks)
+                    const u32x4 h0 = *(const u32x4*)(pp + (kc & 1) * 16), h1 = *(const u32x4*)(pp + ((kc & 1) ^ 1) * 16);
+                    const u32x4 lo4 = (kc & 1) ? h1 : h0, hi4 = (kc & 1) ? h0 : h1;
+                    const u32x4 bw = {__builtin_amdgcn_perm(lo4[1], lo4[0], sel), __builtin_amdgcn_perm(lo4[3], lo4[2], sel),
+                                      __builtin_amdgcn_perm(hi4[1], hi4[0], sel), __builtin_amdgcn_perm(hi4[3], hi4[2], sel)};
+                    P = __builtin_amdgcn_mfma_f32_16x16x32_f16(xo[jj], __builtin_bit_cast(v3h8, bw), P, 0, 0, 0);
+                }
+            }
             // (uniform 0 / 1 factors instead of an if-chain: hipcc turns a run-time choice among four scalars into a
             //  scratch array, whose loads and stores would then sit in the vmcnt queue of the weight ring)
-            acc0 = fmaf(P[0], rs == 0 ? 1.f : 0.f, acc0);
-            acc1 = fmaf(P[0], rs == 1 ? 1.f : 0.f, acc1);
-            acc2 = fmaf(P[0], rs == 2 ? 1.f : 0.f, acc2);
-            acc3 = fmaf(P[0], rs == 3 ? 1.f : 0.f, acc3);
+            const val_t Pv = v3_pick<MB>(P);
+            acc0 = v3_fma(Pv, rs == 0 ? 1.f : 0.f, acc0);
+            acc1 = v3_fma(Pv, rs == 1 ? 1.f : 0.f, acc1);
+            acc2 = v3_fma(Pv, rs == 2 ? 1.f : 0.f, acc2);
+            acc3 = v3_fma(Pv, rs == 3 ? 1.f : 0.f, acc3);
         }
     }
 
     if (nsw > 0) {
         v3h8 xf[4], xn[4];                 // x fragments of the current / next step
-        float alo = 0.f, ahi = 0.f;        // -1024 S_lo, -1024 S_hi of the current step (lanes kc == 0: batch row 0)
+        val_t alo = v3_zero<MB>(), ahi = v3_zero<MB>();        // -1024 S_lo, -1024 S_hi of the current step
         int c_rs = 0, c_i = 0;
         auto load_x = [&](v3h8 (&o)[4], int i) {
             const v3h8* px = (const v3h8*)(xa + (size_t)(wave + i * NW) * 256);
@@ -357,47 +516,48 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         auto scale_word = [&](int rs, int i) {
             return *(const uint32_t*)(szl + (size_t)rs * SZB + (size_t)(per_channel ? 0 : wave + i * NW) * 64 + nl * 4);
         };
-        auto bias_sums = [&](const v3h8 (&x4)[4], float& lo, float& hi) {
-            if (ABL & 1) { lo = hi = 0.f; return; }
+        auto bias_sums = [&](const v3h8 (&x4)[4], val_t& lo, val_t& hi) {
+            if (ABL & 1) { lo = hi = v3_zero<MB>(); return; }
             f32x4 A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[0], c8, z4, 0, 0, 0);
             f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[1], c8, z4, 0, 0, 0);
             A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, A0, 0, 0, 0);
             A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[3], c8, A1, 0, 0, 0);
             if (BITS == 3) {                // one scale class: every 3-bit field is moved to bits 0..2 of its half-word
-                lo = A0[0] + A1[0];
-                hi = 0.f;
+                lo = v3_pick<MB>(A0) + v3_pick<MB>(A1);
+                hi = v3_zero<MB>();
             } else {
-                lo = A0[0];
-                hi = A1[0];
+                lo = v3_pick<MB>(A0);
+                hi = v3_pick<MB>(A1);
             }
         };
         load_x(xf, 0);
         uint32_t szw = scale_word(0, 0);
         bias_sums(xf, alo, ahi);
-        float nlo = 0.f, nhi = 0.f;        // the next step's sums, computed one step ahead
+        val_t nlo = v3_zero<MB>(), nhi = v3_zero<MB>();        // the next step's sums, computed one step ahead
         // Software pipeline: the products of a (step, row set) are folded into the accumulators one consume LATER, behind
         // the MFMAs of the next one -- nothing reads an MFMA result right behind the MFMA (that wait was ~10 % of a launch).
-        float pv_lo = 0.f, pv_hi = 0.f, pv_alo = 0.f, pv_ahi = 0.f, pv_f0 = 0.f, pv_f1 = 0.f, pv_f2 = 0.f, pv_f3 = 0.f;
+        val_t pv_lo = v3_zero<MB>(), pv_hi = v3_zero<MB>(), pv_alo = v3_zero<MB>(), pv_ahi = v3_zero<MB>();
+        float pv_f0 = 0.f, pv_f1 = 0.f, pv_f2 = 0.f, pv_f3 = 0.f;
         uint32_t pv_szw = 0;
         auto fold = [&]() {
             const h2 sz2 = as_h2(pv_szw);
-            const float add = (float)sz2[0] * ((pv_lo + pv_alo) + 0.0625f * (pv_hi + pv_ahi)) +
+            const val_t add = (float)sz2[0] * ((pv_lo + pv_alo) + 0.0625f * (pv_hi + pv_ahi)) +
                               (float)sz2[1] * ((pv_alo + pv_ahi) * -0.0009765625f);
             // (uniform 0 / 1 factors, not an if-chain: see the outlier step)
-            acc0 = fmaf(add, pv_f0, acc0);
-            acc1 = fmaf(add, pv_f1, acc1);
-            acc2 = fmaf(add, pv_f2, acc2);
-            acc3 = fmaf(add, pv_f3, acc3);
+            acc0 = v3_fma(add, pv_f0, acc0);
+            acc1 = v3_fma(add, pv_f1, acc1);
+            acc2 = v3_fma(add, pv_f2, acc2);
+            acc3 = v3_fma(add, pv_f3, acc3);
         };
         auto consume = [&](const ring_t& wv) {
             const bool last_rs = c_rs + 1 >= RS;
             const int ni = c_i + 1 < nsw ? c_i + 1 : c_i;
             if (c_rs == 0) load_x(xn, ni);     // next step's fragments: in flight during this step's RS row sets
             const uint32_t szw_n = scale_word(last_rs ? 0 : c_rs + 1, last_rs ? ni : c_i);
-            float lo, hi;
+            val_t lo, hi;
             if (ABL & 4) {
-                lo = __builtin_bit_cast(float, wv[0] ^ wv[1]);
-                hi = __builtin_bit_cast(float, wv[2] ^ wv[BITS == 3 ? 0 : 3]);
+                lo = v3_zero<MB>() + __builtin_bit_cast(float, wv[0] ^ wv[1]);
+                hi = v3_zero<MB>() + __builtin_bit_cast(float, wv[2] ^ wv[BITS == 3 ? 0 : 3]);
             } else {
                 // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
                 u32x4 bf[4];
@@ -434,11 +594,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                 if (last_rs) bias_sums(xn, nlo, nhi);      // the NEXT step's sums ride behind this step's last products
                 fold();                                     // the PREVIOUS (step, row set): its MFMAs retired long ago
                 if (BITS == 3) {
-                    lo = Plo[0] + Phi[0];
-                    hi = 0.f;
+                    lo = v3_pick<MB>(Plo) + v3_pick<MB>(Phi);
+                    hi = v3_zero<MB>();
                 } else {
-                    lo = Plo[0];
-                    hi = Phi[0];
+                    lo = v3_pick<MB>(Plo);
+                    hi = v3_pick<MB>(Phi);
                 }
             }
             if (ABL & 4) fold();
@@ -473,18 +633,44 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         }
         fold();                                // the last (step, row set)
     }
-    if (ABL & 8) ts[3] = wall_clock64();
-    if (kc == 0) {
-        red[(0 * NW + wave) * 16 + nl] = acc0;
-        if (RS > 1) red[(1 * NW + wave) * 16 + nl] = acc1;
-        if (RS > 2) red[(2 * NW + wave) * 16 + nl] = acc2;
-        if (RS > 3) red[(3 * NW + wave) * 16 + nl] = acc3;
+    V3_STAMP(3);
+    if constexpr (MB == 1) {
+        if (kc == 0) {
+            red[(0 * NW + wave) * 16 + nl] = acc0;
+            if (RS > 1) red[(1 * NW + wave) * 16 + nl] = acc1;
+            if (RS > 2) red[(2 * NW + wave) * 16 + nl] = acc2;
+            if (RS > 3) red[(3 * NW + wave) * 16 + nl] = acc3;
+        }
+    } else {
+        if (kc < 2) {                           // batch rows 4 kc + j
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* r0 = red + ((size_t)(0 * NW + wave) * 8 + 4 * kc + j) * 16 + nl;
+                r0[0] = acc0[j];
+                if (RS > 1) r0[(size_t)1 * NW * 128] = acc1[j];
+                if (RS > 2) r0[(size_t)2 * NW * 128] = acc2[j];
+                if (RS > 3) r0[(size_t)3 * NW * 128] = acc3[j];
+            }
+        }
     }
 
     // ---- 5. combine the waves, finish the norm, fused epilogues
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // step 2b's pieces (a wave without ring steps never waited)
     __syncthreads();
-    if (ABL & 8) ts[5] = wall_clock64();
+    V3_STAMP(5);
+    if constexpr (MB == 2) {
+        // y[i][row] for the m batch rows: wave i takes batch row i (NW >= 8 > m), lane = (row set lane / 16, row lane % 16)
+        const int i = wave, rs = lane >> 4;
+        if (i < m && rs < RS) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[((size_t)(rs * NW + w) * 8 + i) * 16 + nl];
+            const int row = (set0 + rs) * 16 + nl;
+            if (bias) v += (float)bias[row];
+            yout[(size_t)i * G.nsets * 16 + row] = (f16)v;
+        }
+        return;
+    }
     float rs_norm = 1.f;
     if (XN) {
         float sx = 0.f;
@@ -521,9 +707,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
             }
             const f16 g16 = (f16)gv, u16 = (f16)uv;
             const f16 r16 = (f16)(silu_f32((float)g16) * (float)u16);
+#if defined(QEFT_LAB)
             if (ABL & 8) { asm volatile("" :: "v"(r16)); ts[6] = wall_clock64(); }
+#endif
             yout[(set0 + rs) * 8 + n] = r16;
         }
+#if defined(QEFT_LAB)
         if (ABL & 8) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 0) {
@@ -533,6 +722,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                 a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
             }
         }
+#endif
         return;
     }
     float sq = 0.f;
@@ -540,7 +730,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         const int row = set0 * 16 + tid;
         float v = row_sum(tid >> 4, tid & 15);
         if (bias) v += (float)bias[row];
+#if defined(QEFT_LAB)
         if (ABL & 8) { asm volatile("" :: "v"(v)); ts[6] = wall_clock64(); }
+#endif
         if (residual) {
             v += ((const float*)epl)[tid];                          // lanes [0, 16) x 4 floats = the block's RS * 16 rows
             y32[row] = v;
@@ -556,6 +748,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         sq = wave_sum(sq);
         if (lane == 0) ssq_out[blockIdx.x] = sq;
     }
+#if defined(QEFT_LAB)
     if (ABL & 8) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
@@ -565,6 +758,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
             a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
         }
     }
+#endif
 }
 #endif  // __HIPCC__
 

@@ -46,12 +46,15 @@ static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hi
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
+    if constexpr (D == 2 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches, ring depth 2
+        if (a.m > 1) return go(gemv_v3_kernel<NW, 2, OUTL, V3_MODE_PLAIN, 0, 4, 2>);
+    }
     return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR, 0, BITS>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN, 0, BITS>);
 }
 
 template <int NW, bool OUTL, int BITS>
 static hipError_t launch_d(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
-    if (depth == 2) return launch_dm<NW, 2, OUTL, BITS>(a, mode, nblk, smem, st);
+    if (depth == 2 || a.m > 1) return launch_dm<NW, 2, OUTL, BITS>(a, mode, nblk, smem, st);
     if constexpr (NW == 8 && BITS == 4) {      // 16-wave blocks are capped at 128 VGPRs: depth 6 would spill (and has too few steps)
         if (depth == 6) return launch_dm<NW, 6, OUTL, BITS>(a, mode, nblk, smem, st);
     }
@@ -69,26 +72,51 @@ static int env_int(const char* name) {
     return e ? atoi(e) : 0;
 }
 
-hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
+// Geometry of a launch: blocks, row sets per block, waves per block, LDS bytes.  Returns false when the configuration does
+// not fit the chip's 160 KB of LDS per block (many batch rows of a long x: the caller splits the batch).
+static bool gemv_v3_plan(V3Args& a, int& nw, size_t& smem) {
     const int nblk = gemv_v3_blocks(a.g.nsets);
     a.rs_cap = ceil_div(a.g.nsets, nblk);
     a.nblk = nblk;
     a.sets_q = a.g.nsets / nblk;
     a.sets_r = a.g.nsets % nblk;
-    const size_t smem = v3_smem_bytes(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.xn_gamma != nullptr);
-    if (smem > 160 * 1024 || nblk >= 65536) return hipErrorInvalidValue;       // (nblk, sets_r share dwords with rs_cap, sets_q)
+    if (a.m < 1) a.m = 1;
     // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
-    static const int f_nw = env_int("QEFT_GEMV_NW"), f_d = env_int("QEFT_GEMV_DEPTH");     // lab overrides
+    static const int f_nw = env_int("QEFT_GEMV_NW");      // lab override
     // measured (tools/gemv_v3_lab.hip, profiles/r02_gemv_v3_lab.txt, and A/B runs of the whole decode step): 16 waves where a
     // CU holds one block and a wave still has several steps (q|k|v 8.3 vs 9.0 us, down_proj 8.0 vs 8.9); o_proj (2 steps
-    // per wave at 16) keeps 8 waves; two blocks per CU (gate|up) run best at 8 waves.  Ring depth 2 everywhere: gate|up 12.9
-    // vs 14.3 us at depth 4 (16.6 at 6: registers), o_proj 4.72 vs 5.08 with the preloaded prologue, the 3-bit stream likewise
+    // per wave at 16) keeps 8 waves; two blocks per CU (gate|up) run best at 8 waves.
     const int steps16 = ceil_div(a.g.nfull, 16) * a.rs_cap;
-    const int nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 && steps16 >= 4 ? 16 : 8);
+    nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 && steps16 >= 4 ? 16 : 8);
+    a.nw = nw;
+    smem = v3_lds(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.m, nw, a.xn_gamma != nullptr && a.szp != nullptr, a.szp == nullptr, a.ids != nullptr).total;
+    return smem <= 160 * 1024 && nblk < 65536;       // (nblk, sets_r share dwords with rs_cap, sets_q)
+}
+
+// Batch rows one launch of this configuration can take (0: not even one): LDS holds m rows of x (twice with a gather)
+int gemv_v3_max_rows(V3Args a, int m_want) {
+    for (int m = m_want < V3_MAX_M ? m_want : V3_MAX_M; m >= 1; --m) {
+        int nw;
+        size_t smem;
+        a.m = m;
+        if (gemv_v3_plan(a, nw, smem)) return m;
+    }
+    return 0;
+}
+
+hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
+    int nw;
+    size_t smem;
+    if (a.m > V3_MAX_M || !gemv_v3_plan(a, nw, smem)) return hipErrorInvalidValue;
+    if (a.m > 1 && (mode != V3_MODE_PLAIN || a.bits == 3 || a.residual || a.ssq_in || a.xn_gamma)) return hipErrorInvalidValue;
+    if (!a.szp && (a.xn_gamma || !a.scales || !a.zeros)) return hipErrorInvalidValue;     // (the zeros pointer uses xn_gamma's slot)
+    static const int f_d = env_int("QEFT_GEMV_DEPTH");     // lab override
+    // Ring depth 2 everywhere: gate|up 12.9 vs 14.3 us at depth 4 (16.6 at 6: registers), o_proj 4.72 vs 5.08 with the
+    // preloaded prologue, the 3-bit stream likewise
     const int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : 2;
     const bool w3 = a.bits == 3;
-    g_last_variant = mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
-    return w3 ? launch_b<3>(a, mode, nblk, smem, nw, depth, st) : launch_b<4>(a, mode, nblk, smem, nw, depth, st);
+    g_last_variant = a.m > 1 ? "gemv_v3_mb" : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
+    return w3 ? launch_b<3>(a, mode, a.nblk, smem, nw, depth, st) : launch_b<4>(a, mode, a.nblk, smem, nw, depth, st);
 }
 
 // ---- host-side enumeration of every address the kernel can form for a configuration (no GPU involved).
@@ -137,6 +165,49 @@ long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq
                         for (int i = 0; i < (nsw > 0 ? nsw : 1); ++i)
                             bad += set_off + (size_t)rs * set_bytes + step0 + (size_t)i * NW * stepb + lane_off + (bits == 3 ? 12 : 16) > qw_bytes;
                 }
+        }
+    }
+    return bad;
+}
+
+// The same for a launch on the CHECKPOINT-layout operands (the reference's gemv entries): scales / scaled_zeros fp16
+// [ngroups][N], oweight_interleaved [N/2][256], reorder_ids, m batch rows.  Source accesses against the operand sizes, and
+// every LDS destination / LDS read of the staging transforms against the carve-up (v3_lds).
+long long gemv_v3_count_out_of_range_ckpt(const V3Geom& G, int n_rows_have, int m, bool gather) {
+    long long bad = 0;
+    const size_t sc_bytes = (size_t)G.ngroups * n_rows_have * 2, il_bytes = (size_t)(n_rows_have / 2) * 256 * 2,
+                 x_bytes = (size_t)m * G.K * 2, ids_bytes = (size_t)G.K * 4;
+    const int nblk = gemv_v3_blocks(G.nsets), rs_cap = ceil_div(G.nsets, nblk);
+    const int XB = v3_x_bytes(G.K), SRB = v3_szraw_bytes(G.ngroups), XS = v3_x_stride(G.K, m);
+    // (the strided scale rows assume the operand really has G.nsets * 16 columns: a shrunk operand is the negative control)
+    for (int nw = 8; nw <= 16; nw += 8) {
+        const V3Lds L = v3_lds(G.K, G.ngroups, G.n_out, rs_cap, m, nw, false, true, gather);
+        if (L.total > 160 * 1024) continue;     // not launched (gemv_v3_plan)
+        for (int b = 0; b < nblk; ++b) {
+            int set0, RS;
+            v3_block_sets(v3_xcd_block(b, nblk), G.nsets / nblk, G.nsets % nblk, set0, RS);
+            for (int lane = 0; lane < 64; ++lane) {
+                for (int i = 0; i < m; ++i)
+                    for (int p = 0; p < (XB >> 10); ++p) {
+                        bad += (size_t)i * G.K * 2 + v3_x_off(G, p, lane) + 16 > x_bytes;
+                        const uint32_t dst = (gather ? L.xraw + (uint32_t)i * XB : L.xs + (uint32_t)i * XS) + ((uint32_t)p << 10) + lane * 16;
+                        bad += dst + 16 > (gather ? L.total : L.szl);
+                    }
+                if (gather)
+                    for (int p = 0; p < (v3_xf_bytes(G.K) >> 10); ++p) {
+                        bad += (size_t)v3_xf_off(G, p, lane) + 16 > ids_bytes;
+                        bad += L.idsl + ((uint32_t)p << 10) + lane * 16 + 16 > L.xraw;
+                    }
+                for (int rs = 0; rs < RS; ++rs) {
+                    for (int arr = 0; arr < 2; ++arr)
+                        for (int j = 0; j < (SRB >> 10); ++j) {
+                            bad += v3_szn_off(G, set0 + rs, j, lane) + 16 > sc_bytes;
+                            bad += L.szraw + (uint32_t)(arr * rs_cap + rs) * SRB + ((uint32_t)j << 10) + lane * 16 + 16 > L.idsl;
+                        }
+                    if (G.n_out > 0)
+                        for (int j = 0; j < 4; ++j) bad += v3_owil_off(set0 + rs, j, lane) + 16 > il_bytes;
+                }
+            }
         }
     }
     return bad;

@@ -11,8 +11,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def run_case(n, k, r, g, m, seed, bias=False, gather=False, residual=False, fused=True):
-    from qeft_amd import qeft_cuda
+def v3_takes(n, k, r, g, residual=False):
+    """Shapes the reference's gemv entries route to the round-2 kernel (include/qeft_hip.h, "Kernel reached by ...")."""
+    return n % 16 == 0 and k % 128 == 0 and g in (128, k) and (r == 0 or (r == 128 and k > 128)) and not residual
+
+
+def run_case(n, k, r, g, m, seed, bias=False, gather=False, residual=False, fused=True, szp=False):
+    from qeft_amd import _lib, qeft_cuda
     bufs = O.make_layer(n, k, r, g, seed=seed, bias=bias)
     x = O.make_activation(m, k, r, seed=seed)
     t = layer_to_torch(bufs, DEV)
@@ -32,17 +37,24 @@ def run_case(n, k, r, g, m, seed, bias=False, gather=False, residual=False, fuse
         y = qeft_cuda.gemv_4bit_fused(xt, t["qweight"], t["scales"], t["scaled_zeros"],
                                       t.get("oweight_interleaved") if r else None, t.get("bias"),
                                       torch.from_numpy(ids.astype(np.int32)).to(DEV) if ids is not None else None,
-                                      torch.from_numpy(res).to(DEV) if res is not None else None, m, n, k, g)
+                                      torch.from_numpy(res).to(DEV) if res is not None else None, m, n, k, g,
+                                      qeft_cuda.pack_scales(t["scales"], t["scaled_zeros"], n, k, g) if szp else None)
     elif r:
         y = qeft_cuda.gemv_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"],
                                      m, n, k, g)
     else:
         y = qeft_cuda.gemv_4bit(xt, t["qweight"], t["scales"], t["scaled_zeros"], m, n, k, g)
+    variant = _lib.last_variant()
     torch.cuda.synchronize()
     y = y.cpu().numpy()
     assert y.shape == (m, n) and y.dtype == np.float16
-    assert rel_err(y, yref) < REL_TOL, (rel_err(y, yref), n, k, r, g, m)
-    assert elem_err_ok(y, yref)
+    assert rel_err(y, yref) < REL_TOL, (rel_err(y, yref), n, k, r, g, m, variant)
+    assert elem_err_ok(y, yref), (n, k, r, g, m, variant)
+    if v3_takes(n, k, r, g, residual):
+        # (a batch whose x rows do not fit the block's LDS is split into several launches; the last one names the variant)
+        assert variant in ("gemv_v3", "gemv_v3_mb") and (m > 1 or variant == "gemv_v3"), (variant, n, k, r, g, m)
+    else:
+        assert variant in ("gemv_mfma", "gemv_valu"), (variant, n, k, r, g, m)
     return y
 
 
@@ -71,6 +83,49 @@ def test_gemv_shapes_and_groups(n, k, r, g):
                                  (5120, 13824)])
 def test_gemv_llama_shapes(n, k):
     run_case(n, k, 128, 128, 1, seed=7)
+
+
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008), (5120, 5120), (13824, 5120),
+                                 (5120, 13824)])
+def test_reference_entry_batches_1_to_7_on_llama_shapes(n, k):
+    """gemv_4bit_qeft as the reference calls it (qlinear.py:253-263; m switch gemv_cuda_qeft.cu:433-466), m = 1..7 on the six
+    Llama-2 7B / 13B shapes: one packed layer, every batch size, the round-2 kernel asserted (run_case)."""
+    from qeft_amd import _lib, qeft_cuda
+    r, g = 128, 128
+    bufs = O.make_layer(n, k, r, g, seed=n // 16 + k)
+    t = layer_to_torch(bufs, DEV)
+    w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], g).astype(np.float32)
+    for m in range(1, 8):
+        x = O.make_activation(m, k, r, seed=100 + m)
+        y = qeft_cuda.gemv_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                     t["oweight_interleaved"], m, n, k, g)
+        variant = _lib.last_variant()
+        torch.cuda.synchronize()
+        yref = x.astype(np.float64) @ w.astype(np.float64).T
+        # (K = 11008 / 13824: seven rows of x exceed the block's LDS and go as 4 + 3 or 3 + 3 + 1 rows: the last launch names the variant)
+        assert variant == "gemv_v3" if m == 1 else variant in ("gemv_v3_mb", "gemv_v3"), (variant, m)
+        assert variant == "gemv_v3_mb" or m == 1 or k > 8192, (variant, m)
+        assert rel_err(y.cpu().numpy(), yref) < REL_TOL, (m, rel_err(y.cpu().numpy(), yref))
+        assert elem_err_ok(y.cpu().numpy(), yref), m
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 7])
+def test_reference_entries_no_outliers_and_per_channel(m):
+    """gemv_4bit (no outlier slice) and a per-channel layer (group == K: scales [1][N]) on the round-2 kernel."""
+    run_case(4096, 4096, 0, 128, m, seed=20 + m, fused=False)
+    run_case(512, 2048, 128, 2048, m, seed=30 + m, fused=False)
+    run_case(16 * 513, 256, 128, 128, m, seed=40 + m, fused=False)     # row sets that do not divide over the blocks, one INT4 step
+    run_case(48, 384, 0, 128, m, seed=50 + m, fused=False)
+
+
+@pytest.mark.parametrize("m", [1, 3, 7])
+def test_fused_entry_gather_bias_and_shadow(m):
+    """QuantLinear.forward_outlier_out_proj's launch (qlinear.py:273-300): the reorder_ids gather inside the v3 launch, with
+    the bias, with and without the sz_packed shadow; N = 11008 puts several row sets on a block."""
+    run_case(4096, 4096, 128, 128, m, seed=60 + m, bias=True, gather=True)
+    run_case(4096, 4096, 128, 128, m, seed=61 + m, gather=True, szp=True)
+    run_case(11008, 4096, 128, 128, m, seed=62 + m, bias=True, szp=True)
+    run_case(1376, 5120, 128, 128, m, seed=63 + m, bias=True, gather=True)
 
 
 def test_gemv_fused_bias_gather_residual():
