@@ -268,6 +268,68 @@ def gemm_records(dev, m=2048, layers=4, reps=25):
     return fwd_recs, ft_recs
 
 
+def boundary_gemv_records(dev, sets=8, reps=20):
+    """boundary_gemv: the reference's own entry points for < 8 rows, timed as a user of the reference reaches them --
+    `qeft_cuda.gemv_4bit_qeft(x, qweight, scales, scaled_zeros, oweight_interleaved, m, N, K, G)` (qlinear.py:253-263) and
+    `QuantLinear.forward` (forward_outlier; forward_outlier_out_proj with its reorder_ids gather for the o_proj record) at
+    m = 1 and 4 on the three 7B shapes.  `sets` distinct weight sets are cycled (nothing is served from L2 / MALL), the
+    calls -- output allocation included -- are captured into a graph and replayed; HIP-event time per call, algorithmic
+    bytes per call, and the kernel variant the call reached."""
+    import torch
+    from qeft_amd import _lib, qeft_cuda
+    from qeft_amd.qlinear import QuantLinear, pack_oweight
+    r, g = 128, 128
+    recs = []
+    for (n, k) in SHAPES_7B:
+        mods = []
+        for i in range(sets):
+            ql = QuantLinear(4, k, n, False, torch.float16, r, g, True, "mlp.proj")
+            ql.qweight = torch.randint(-32768, 32767, (n // 4, k), dtype=torch.int16, device=dev)
+            ql.scales = (torch.rand(k // g, n, device=dev) * 0.004 + 0.001).half()
+            ql.scaled_zeros = (-(torch.rand(k // g, n, device=dev) * 8 + 4) * ql.scales.float()).half()
+            ql.oweight = (torch.randn(n, r, device=dev) * 0.02).half()
+            ql.oweight_interleaved = pack_oweight(ql.oweight)
+            ql.outlieridx = torch.sort(torch.randperm(k, device=dev)[:r]).values.to(torch.int32)
+            ql.set_kernel()
+            mods.append(ql)
+        oproj = None
+        if (n, k) == (4096, 4096):          # the o_proj form of the same layers: forward gathers x[:, reorder_ids] first (qlinear.py:275)
+            oproj = []
+            for ql in mods:
+                qo = QuantLinear(4, k, n, False, torch.float16, r, g, True, "self_attn.o_proj")
+                for nm in ("qweight", "scales", "scaled_zeros", "oweight", "oweight_interleaved", "outlieridx"):
+                    setattr(qo, nm, getattr(ql, nm))
+                qo.set_kernel()
+                oproj.append(qo)
+        rec = {"shape": f"{n}x{k}"}
+        for m in (1, 4):
+            x = torch.randn(m, k, device=dev).half()
+            nbytes = n * (k - r) // 2 + 2 * (k // g) * n * 2 + n * r * 2 + 2 * m * k + 2 * m * n
+            calls = {"gemv_4bit_qeft": lambda ql: qeft_cuda.gemv_4bit_qeft(x, ql.qweight, ql.scales, ql.scaled_zeros,
+                                                                          ql.oweight_interleaved, m, n, k, g),
+                     "QuantLinear.forward": lambda ql: ql.forward(x)}
+            for tag, call in calls.items():
+                for which, ms in (("", mods), ("_o_proj", oproj)):
+                    if ms is None or (which and tag != "QuantLinear.forward"):
+                        continue
+                    for ql in ms:                       # warm (lazy buffers, attribute set-up) outside the capture
+                        call(ql)
+                    variant = _lib.last_variant()
+                    torch.cuda.synchronize(dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        outs = [call(ql) for ql in ms]
+                    us = _event_time_us(graph.replay, reps, dev) / len(ms)
+                    del graph, outs
+                    rec[f"m{m}_{tag}{which}"] = {"us": round(us, 2), "GB/s": round(nbytes / us / 1e3, 1), "variant": variant}
+        recs.append(rec)
+        del mods, oproj
+        torch.cuda.empty_cache()
+    return {"per_shape": recs, "weight_sets_cycled": sets,
+            "note": "the reference's entry points as qlinear.py calls them, graph-replayed incl. the output allocation; "
+                    "bytes = algorithmic bytes of the call (SURVEY 8d) with m rows of x and y"}
+
+
 # ---------------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -305,7 +367,7 @@ def main():
     base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B,
             "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
     ctx0 = CONTEXT + args.warmup                                   # position of the first timed token
-    shape = dataclasses.replace(base, max_seq=max(512, (ctx0 + args.steps + 8 + 15) // 16 * 16), bits=args.bits)
+    shape = dataclasses.replace(base, max_seq=max(512, (ctx0 + args.steps + 128 + 8 + 15) // 16 * 16), bits=args.bits)
 
     t_build = time.time()
     model = QuantLlama(shape, dev, seed=0, fast_init=True)
@@ -358,6 +420,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last_tok = int(eng.tok.item())
+    # steady_128: 128 further timed tokens on the same graphs (rewound to the protocol's context, one untimed pass first so that
+    # nothing is captured inside the timed one) -- shows whether a short --steps run is representative
+    steady = None
+    if world == 1 and graph_ok:
+        extra_n = 128
+        for timed in (False, True):
+            eng.set_position(ctx0)
+            eng.tok.fill_(1)
+            barrier()
+            t1 = time.perf_counter()
+            eng.run(extra_n)
+            barrier()
+            if timed:
+                steady = {"tokens": extra_n, "tokens_per_s": round(extra_n / (time.perf_counter() - t1), 2),
+                          "ms_per_step": round((time.perf_counter() - t1) * 1e3 / extra_n, 4)}
 
     # ---- roofline of the dominant kernel: the token's GEMV launches alone, back to back, HIP-event timed
     roof = None
@@ -409,6 +486,7 @@ def main():
         if rank == 0:
             print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
 
+    tp3 = bool(getattr(eng, "tp3", False))      # (the extras below free the engine)
     extras = {}
     if world == 1 and not args.no_extras:
         # ---- the reference's per-token protocol: synchronize after every token, median / min, tokens/s = 1 / median
@@ -437,6 +515,12 @@ def main():
             extras["latency_protocol"] = lat
         except Exception as e:
             print(f"[bench] latency protocol failed: {type(e).__name__}: {e}", file=sys.stderr)
+        # ---- the reference's entry points for < 8 rows: gemv_4bit_qeft / QuantLinear.forward, m = 1 and 4
+        if args.model == "7b" and args.bits == 4:
+            try:
+                extras["boundary_gemv"] = boundary_gemv_records(dev)
+            except Exception as e:
+                print(f"[bench] boundary_gemv failed: {type(e).__name__}: {e}", file=sys.stderr)
         # ---- BASELINE configs 3 and 5 at M = 2048 (7B shapes, w4 operands)
         if args.model == "7b":
             try:
@@ -477,12 +561,14 @@ def main():
                        "layers": shape.n_layers, "hipgraph": graph_ok,
                        "parallelism": ((f"tp{world}: q/k/v/gate/up row-sharded, o/down column-sharded + one all-reduce each "
                                         f"(2 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})")
-                                       if getattr(eng, "tp3", False) else
+                                       if tp3 else
                                        (f"tp{world}: every linear row-sharded, one all-gather each "
                                         f"(4 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})"))
                        if group is not None else "single GPU",
                        "build_s": round(t_build, 1), "last_token": last_tok},
         }
+        if steady:
+            out["steady_128"] = steady
         if roof:
             out["roofline"] = roof
         out.update(extras)
