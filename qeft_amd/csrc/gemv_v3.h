@@ -251,16 +251,35 @@ template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_zero() 
 __device__ __forceinline__ float v3_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ f32x4 v3_fma(const f32x4& a, float b, const f32x4& c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
 
+// compile-time loop over 0 .. N-1 (indices as integral constants: ring slots, row sets and accumulators stay in registers)
+template <int I, int N, typename F> __device__ __forceinline__ void v3_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        v3_static_for<I + 1, N>(f);
+    }
+}
+__host__ __device__ constexpr int v3_gcd(int a, int b) { return b == 0 ? a : v3_gcd(b, a % b); }
+// steps per unrolled round: even (the x fragments alternate between two register sets) and a whole number of ring turns
+__host__ __device__ constexpr int v3_unroll_steps(int D, int RSC) {
+    const int t = D / v3_gcd(D, RSC);
+    return t % 2 == 0 ? t : 2 * t;
+}
+
 // NW waves per block (8, or 16 for launches of one block per CU: twice the instruction streams per SIMD for the same bytes);
 // wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
 // MB: 1 = one batch row (the decode engine, and m = 1 at the reference's entry points); 2 = up to V3_MAX_M batch rows.
-template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1>
+// RSC: 16-row sets per block, a COMPILE-TIME constant (round 3): every (step, row set) of the wave's sequence then has its ring
+//      slot, accumulator and scale row fixed in the code -- the run-time bookkeeping of round 2's loop (which set is next, 0 / 1
+//      factors in front of four accumulators, three branches per consume) was a third of its ~95 instructions per 1 KB of
+//      weights.  A launch's blocks hold RSC sets, except at most RSC - 1 blocks that hold one fewer (gemv_v3_blocks): those
+//      stream their last set twice and drop the copy's results.
+template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1>
 __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
-    static_assert(D % 2 == 0, "ring depth must be even: LDS operand sets alternate per slot");
     static_assert(BITS == 4 || BITS == 3, "4-bit checkpoint layout or the 3-bit extension layout (oracle: pack_w3)");
     static_assert(MB == 1 || (MODE == V3_MODE_PLAIN && BITS == 4), "several batch rows: plain 4-bit launches only");
+    static_assert(RSC >= 1 && RSC <= V3_MAX_RS && D >= 2, "row sets per block 1..4, at least two loads in flight per wave");
     typedef typename V3Val<MB>::type val_t;
     // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
     // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     const bool SZN = (nblk_rscap_flags & V3_F_SZN) != 0, OWIL = OUTL && (nblk_rscap_flags & V3_F_OWIL) != 0;
     const bool GATHER = (nblk_rscap_flags & V3_F_GATHER) != 0;
     const int m = MB == 1 ? 1 : (int)((nblk_rscap_flags >> V3_F_M_SHIFT) & 7u) + 1;
-    const int nblk = (int)(nblk_rscap_flags & 0xffffu), rs_cap = (int)((nblk_rscap_flags >> 16) & 0xffu);
+    const int nblk = (int)(nblk_rscap_flags & 0xffffu);
     const int sets_q = (int)(setsq_setsr & 0xffffu), sets_r = (int)(setsq_setsr >> 16);
     // (nsets from the preloaded words: the checkpoint-layout scale pieces need N before the tail has arrived)
     V3Geom G{K_, a.n_out, a.nsteps, (K_ >> 7) - (OUTL ? 1 : 0), per_channel_f ? 1 : (K_ >> 7), sets_q * nblk + sets_r};
@@ -285,27 +304,28 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     const uint8_t* const residual = (const uint8_t*)a.residual;
     const uint8_t* const gamma_out = (const uint8_t*)a.gamma_out;
     const uint8_t* const idsp = (const uint8_t*)a.ids;
-    asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(rs_cap), "s"(nblk), "s"(sets_q), "s"(sets_r), "s"(xptr), "s"(qw),
+    asm volatile("" ::"s"(G.K), "s"(G.nfull), "s"(G.ngroups), "s"(nblk), "s"(sets_q), "s"(sets_r), "s"(xptr), "s"(qw),
                  "s"(szp), "s"(ow), "s"(xn_gamma));
 
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
-    const V3Lds L = v3_lds(G.K, G.ngroups, OUTL ? 128 : 0, rs_cap, m, NW, XN, SZN, GATHER);
+    const V3Lds L = v3_lds(G.K, G.ngroups, OUTL ? 128 : 0, RSC, m, NW, XN, SZN, GATHER);
     const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups), XS = v3_x_stride(G.K, m);
     uint8_t* const xs = smem + L.xs;                                  // [m][K] fp16 raw (rows XS apart)
-    uint8_t* const szl = smem + L.szl;                                // [rs_cap][SZB / 64][16] u32
-    uint8_t* const owl = smem + L.owl;                                // [rs_cap] 4 KB: 16 plain rows (chunks ^ row) or 8 interleaved rows
+    uint8_t* const szl = smem + L.szl;                                // [RSC][SZB / 64][16] u32
+    uint8_t* const owl = smem + L.owl;                                // [RSC] 4 KB: 16 plain rows (chunks ^ row) or 8 interleaved rows
     uint8_t* const epl = smem + L.epl;                                // [64 lanes][16 B]: residual | gamma_out of the block's rows
     float* const ssql = (float*)(smem + L.ssql);                      // [512] ssq_in
-    float* const red = (float*)(smem + L.red);                        // [rs_cap][NW][16], or [rs_cap][NW][8][16] (MB == 2)
-    uint8_t* const xf = smem + L.xf;                                  // xn launches: [K] fp32 h, then its gamma [K] fp16
+    float* const red = (float*)(smem + L.red);                        // [RSC][NW][16], or [RSC][NW][8][16] (MB == 2)
+    uint8_t* const xf32 = smem + L.xf;                                // xn launches: [K] fp32 h, then its gamma [K] fp16
     uint8_t* const xg = smem + L.xg;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 15, kc = lane >> 4;
-    int set0, RS;
+    int set0, RS;                                                     // RS = RSC, or RSC - 1 in a short block
     v3_block_sets(v3_xcd_block(blockIdx.x, nblk), sets_q, sets_r, set0, RS);
+    auto set_of = [&](int rs) { return set0 + (rs < RS ? rs : RS - 1); };      // a short block's last slot repeats its last set
 #if defined(QEFT_LAB)
     long long ts[7] = {0, 0, 0, 0, 0, 0, 0};    // ABL & 8: entry, ring issued, staging landed (barrier), steps done, (end), all waves done (barrier), values ready
 #endif
@@ -315,7 +335,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
     //         wait for until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
     const int PX = XB >> 10, SPS = SZB >> 10;
-    if (!XN) {
+    if (ABL & 16) {
+        // lab: no staging at all (the results are garbage) -- what the whole staging prologue costs
+    } else if (!XN) {
         // (a gathering launch stages the rows as they are into xraw; step 3b writes xs)
         const uint32_t xdst = lds0 + (GATHER ? L.xraw : L.xs), xstr = GATHER ? (uint32_t)XB : (uint32_t)XS;
         for (int i = 0; i < m; ++i)
@@ -325,57 +347,59 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         const int PF = v3_xf_bytes(G.K) >> 10;
         for (int p = wave; p < PF + PX; p += NW) {
             if (p < PF)
-                v3_dma16(xptr + v3_xf_off(G, p, lane), __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xf + ((uint32_t)p << 10)));
+                v3_dma16(xptr + v3_xf_off(G, p, lane), __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xf32 + ((uint32_t)p << 10)));
             else
                 v3_dma16((const uint8_t*)xn_gamma + v3_x_off(G, p - PF, lane),
                          __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xg + ((uint32_t)(p - PF) << 10)));
         }
     }
     const int SRB = v3_szraw_bytes(G.ngroups), SPR = SRB >> 10;
-    for (int rs = 0; rs < RS; ++rs) {
-        if (!SZN) {
-            for (int j = wave; j < SPS; j += NW)
-                v3_dma16(szp + v3_sz_off(G, set0 + rs, j, lane),
-                         __builtin_amdgcn_readfirstlane(lds0 + L.szl + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
-        } else {            // checkpoint layout: scales (array 0, the szp slot) and scaled_zeros (array 1, the xn_gamma slot), packed in step 3b
-            for (int t = wave; t < 2 * SPR; t += NW) {
-                const int arr = t >= SPR ? 1 : 0, j = t - arr * SPR;
-                v3_dma16((arr ? (const uint8_t*)xn_gamma : szp) + v3_szn_off(G, set0 + rs, j, lane),
-                         __builtin_amdgcn_readfirstlane(lds0 + L.szraw + (uint32_t)(arr * rs_cap + rs) * SRB + ((uint32_t)j << 10)));
+    if (!(ABL & 16)) {
+#pragma unroll
+        for (int rs = 0; rs < RSC; ++rs) {
+            const int set = set_of(rs);
+            if (!SZN) {
+                for (int j = wave; j < SPS; j += NW)
+                    v3_dma16(szp + v3_sz_off(G, set, j, lane), __builtin_amdgcn_readfirstlane(lds0 + L.szl + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
+            } else {        // checkpoint layout: scales (array 0, the szp slot) and scaled_zeros (array 1, the xn_gamma slot), packed in step 3b
+                for (int t = wave; t < 2 * SPR; t += NW) {
+                    const int arr = t >= SPR ? 1 : 0, j = t - arr * SPR;
+                    v3_dma16((arr ? (const uint8_t*)xn_gamma : szp) + v3_szn_off(G, set, j, lane),
+                             __builtin_amdgcn_readfirstlane(lds0 + L.szraw + (uint32_t)(arr * RSC + rs) * SRB + ((uint32_t)j << 10)));
+                }
             }
+            if (OUTL && wave >= NW - 4)
+                v3_dma16(ow + (OWIL ? v3_owil_off(set, wave - (NW - 4), lane) : v3_ow_off(set, wave - (NW - 4), lane)),
+                         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - (NW - 4)) << 10)));
         }
-        if (OUTL && wave >= NW - 4)
-            v3_dma16(ow + (OWIL ? v3_owil_off(set0 + rs, wave - (NW - 4), lane) : v3_ow_off(set0 + rs, wave - (NW - 4), lane)),
-                     __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - (NW - 4)) << 10)));
     }
 
     // ---- 2. weight stream: ring of D loads per wave, branch-free, oldest first.  The wave's work is the sequence
-    //         t = 0 .. nsw*RS-1 of (step wave + NW (t / RS), row set t % RS): STEP-major, so the x fragments and the bias
-    //         sums of a step are fetched / computed once and serve all RS row sets.  Issues past the end re-read a valid address.
+    //         c = 0 .. nsw * RSC - 1 of (step wave + NW (c / RSC), row set c % RSC): STEP-major, so the x fragments and the bias
+    //         sums of a step are fetched / computed once and serve all RSC row sets; load c goes to ring slot c % D.  The D
+    //         issues past the end re-read the wave's last step (a valid address).
     const int nsw = (G.nfull - wave + NW - 1) / NW;
     constexpr uint32_t STEPB = BITS == 3 ? 768u : 256u;              // bytes from one 128-k step of a row (group) to the next
     const uint32_t set_bytes = BITS == 3 ? (uint32_t)G.nfull * 768u : (uint32_t)G.K * 8u;   // one 16-row set
     const uint8_t* const wbase = qw + (BITS == 3 ? v3w3_set_off(G, set0) : v3_w_set_off(G, set0));         // wave-uniform
     const uint32_t lane_off = BITS == 3 ? (uint32_t)lane * 12u : v3_w_lane_off(G, nl, kc);
     const uint32_t step0 = min((uint32_t)wave * STEPB, BITS == 3 ? v3w3_last_step_off(G) : v3_last_step_off(G));
+    const uint32_t step_last = step0 + (uint32_t)(nsw > 0 ? nsw - 1 : 0) * (NW * STEPB);
+    const uint32_t short_back = RS < RSC ? set_bytes : 0u;           // a short block's last slot: back to its last real set
     typedef typename std::conditional<BITS == 3, u32x3_u, u32x4>::type ring_t;
     ring_t ring[D];
-    int p_rs = 0, p_i = 0;
-    uint32_t p_off = step0;                                          // uniform byte offset of the next issue
-    auto issue = [&](ring_t& b) {
-        b = __builtin_nontemporal_load((const ring_t*)(wbase + p_off + lane_off));
-        p_off += set_bytes;
-        if (++p_rs >= RS) {                                          // next step (or, past the end, the last one again)
-            p_rs = 0;
-            if (p_i + 1 < nsw) ++p_i;
-            p_off = step0 + (uint32_t)p_i * (NW * STEPB);
-        }
+    uint32_t p_step = step0;                                         // uniform byte offset of the step the next issue reads
+    // issue of load number c (its row set is a compile-time constant; the step advances behind a step's last row set)
+    auto issue = [&](ring_t& b, auto rs_tag) {
+        constexpr int rs = decltype(rs_tag)::value;
+        const uint32_t off = p_step + (uint32_t)rs * set_bytes - (rs == RSC - 1 ? short_back : 0u);
+        b = __builtin_nontemporal_load((const ring_t*)(wbase + off + lane_off));
+        if (rs == RSC - 1) p_step = min(p_step + NW * STEPB, step_last);
     };
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        issue(ring[d]);
+    v3_static_for<0, D>([&](auto d) {
+        issue(ring[d], std::integral_constant<int, decltype(d)::value % RSC>{});
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 
     asm volatile("" ::"s"(G.nsteps), "s"(ssq_n), "s"(ssq_in), "s"(residual), "s"(gamma_out), "s"(eps), "s"(bias), "s"(yout), "s"(y32),
                  "s"(ynorm), "s"(ssq_out), "s"(idsp));
@@ -410,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     float xn_ss = 0.f;
     if (XN) {
         for (int e = tid * 4; e < G.K; e += NW * 64 * 4) {
-            const f32x4 hv = *(const f32x4*)(xf + (size_t)e * 4);
+            const f32x4 hv = *(const f32x4*)(xf32 + (size_t)e * 4);
             const h4 gv = *(const h4*)(xg + (size_t)e * 2);
             h4 o;
 #pragma unroll
@@ -439,8 +463,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     }
     if (SZN) {
         const uint8_t* const sraw = smem + L.szraw;
-        const uint8_t* const zraw = sraw + (size_t)rs_cap * SRB;
-        for (int rs = 0; rs < RS; ++rs)
+        const uint8_t* const zraw = sraw + (size_t)RSC * SRB;
+        for (int rs = 0; rs < RSC; ++rs)
             for (int q = tid; q < G.ngroups * 4; q += NW * 64) {     // q = (group, 4 rows)
                 const u32x2 sv = *(const u32x2*)(sraw + (size_t)rs * SRB + (size_t)q * 8);
                 const u32x2 zv = *(const u32x2*)(zraw + (size_t)rs * SRB + (size_t)q * 8);
@@ -454,7 +478,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
 
     // ---- 4. steps.  acc[rs]: lanes kc == 0 hold row nl of row set rs (batch row 0 = D row 0, register 0); MB == 2: every lane
     //         holds the batch rows 4 kc .. 4 kc + 3 (D rows) of row nl
-    val_t acc0 = v3_zero<MB>(), acc1 = v3_zero<MB>(), acc2 = v3_zero<MB>(), acc3 = v3_zero<MB>();
+    val_t acc[RSC];
+    v3_static_for<0, RSC>([&](auto r) { acc[r] = v3_zero<MB>(); });
     uint32_t MAGIC = 0x64006400u, NEG1024 = 0xE400E400u;
     asm volatile("" : "+v"(MAGIC), "+v"(NEG1024));
     const v3h8 c8 = __builtin_bit_cast(v3h8, u32x4{NEG1024, NEG1024, NEG1024, NEG1024});
@@ -474,7 +499,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         // (nl % 8 < 4) or odd halves of every dword; MFMA jj needs the 32 bytes of pair q = 4 kc + jj, stored at pair q ^ R
         const int R = ((nl >> 3) << 2) | (nl & 3);
         const uint32_t sel = (nl & 4) ? 0x07060302u : 0x05040100u;
-        for (int rs = 0; rs < RS; ++rs) {
+        v3_static_for<0, RSC>([&](auto rs_tag) {
+            constexpr int rs = decltype(rs_tag)::value;
             f32x4 P = z4;
             if (!OWIL) {
                 const uint8_t* prow = owl + rs * 4096 + nl * 256;
@@ -494,27 +520,22 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                     P = __builtin_amdgcn_mfma_f32_16x16x32_f16(xo[jj], __builtin_bit_cast(v3h8, bw), P, 0, 0, 0);
                 }
             }
-            // (uniform 0 / 1 factors instead of an if-chain: hipcc turns a run-time choice among four scalars into a
-            //  scratch array, whose loads and stores would then sit in the vmcnt queue of the weight ring)
-            const val_t Pv = v3_pick<MB>(P);
-            acc0 = v3_fma(Pv, rs == 0 ? 1.f : 0.f, acc0);
-            acc1 = v3_fma(Pv, rs == 1 ? 1.f : 0.f, acc1);
-            acc2 = v3_fma(Pv, rs == 2 ? 1.f : 0.f, acc2);
-            acc3 = v3_fma(Pv, rs == 3 ? 1.f : 0.f, acc3);
-        }
+            acc[rs] = acc[rs] + v3_pick<MB>(P);
+        });
     }
 
     if (nsw > 0) {
-        v3h8 xf[4], xn[4];                 // x fragments of the current / next step
+        v3h8 xA[4], xB[4];                 // x fragments of two consecutive steps (the roles alternate step by step)
         val_t alo = v3_zero<MB>(), ahi = v3_zero<MB>();        // -1024 S_lo, -1024 S_hi of the current step
-        int c_rs = 0, c_i = 0;
-        auto load_x = [&](v3h8 (&o)[4], int i) {
-            const v3h8* px = (const v3h8*)(xa + (size_t)(wave + i * NW) * 256);
+        val_t nlo = v3_zero<MB>(), nhi = v3_zero<MB>();        // the next step's sums, computed one step ahead
+        // LDS addresses of the wave's current step: x fragments (256 B per step) and the set-0 scale words (64 B per step / group)
+        const uint8_t* xp = xa + (size_t)wave * 256;
+        const uint8_t* sp = szl + (size_t)(per_channel ? 0 : wave) * 64 + nl * 4;
+        const uint32_t s_stride = per_channel ? 0u : NW * 64u;
+        auto load_x = [&](v3h8 (&o)[4], const uint8_t* p) {
+            const v3h8* px = (const v3h8*)p;
 #pragma unroll
             for (int w = 0; w < 4; ++w) o[w] = px[w];
-        };
-        auto scale_word = [&](int rs, int i) {
-            return *(const uint32_t*)(szl + (size_t)rs * SZB + (size_t)(per_channel ? 0 : wave + i * NW) * 64 + nl * 4);
         };
         auto bias_sums = [&](const v3h8 (&x4)[4], val_t& lo, val_t& hi) {
             if (ABL & 1) { lo = hi = v3_zero<MB>(); return; }
@@ -530,31 +551,28 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                 hi = v3_pick<MB>(A1);
             }
         };
-        load_x(xf, 0);
-        uint32_t szw = scale_word(0, 0);
-        bias_sums(xf, alo, ahi);
-        val_t nlo = v3_zero<MB>(), nhi = v3_zero<MB>();        // the next step's sums, computed one step ahead
+        load_x(xA, xp);
+        uint32_t szw = *(const uint32_t*)sp;                   // scale word of the next consume
+        bias_sums(xA, alo, ahi);
         // Software pipeline: the products of a (step, row set) are folded into the accumulators one consume LATER, behind
         // the MFMAs of the next one -- nothing reads an MFMA result right behind the MFMA (that wait was ~10 % of a launch).
         val_t pv_lo = v3_zero<MB>(), pv_hi = v3_zero<MB>(), pv_alo = v3_zero<MB>(), pv_ahi = v3_zero<MB>();
-        float pv_f0 = 0.f, pv_f1 = 0.f, pv_f2 = 0.f, pv_f3 = 0.f;
         uint32_t pv_szw = 0;
-        auto fold = [&]() {
+        auto fold = [&](val_t& dst) {
             const h2 sz2 = as_h2(pv_szw);
-            const val_t add = (float)sz2[0] * ((pv_lo + pv_alo) + 0.0625f * (pv_hi + pv_ahi)) +
-                              (float)sz2[1] * ((pv_alo + pv_ahi) * -0.0009765625f);
-            // (uniform 0 / 1 factors, not an if-chain: see the outlier step)
-            acc0 = v3_fma(add, pv_f0, acc0);
-            acc1 = v3_fma(add, pv_f1, acc1);
-            acc2 = v3_fma(add, pv_f2, acc2);
-            acc3 = v3_fma(add, pv_f3, acc3);
+            dst = dst + ((float)sz2[0] * ((pv_lo + pv_alo) + 0.0625f * (pv_hi + pv_ahi)) + (float)sz2[1] * ((pv_alo + pv_ahi) * -0.0009765625f));
         };
-        auto consume = [&](const ring_t& wv) {
-            const bool last_rs = c_rs + 1 >= RS;
-            const int ni = c_i + 1 < nsw ? c_i + 1 : c_i;
-            if (c_rs == 0) load_x(xn, ni);     // next step's fragments: in flight during this step's RS row sets
-            const uint32_t szw_n = scale_word(last_rs ? 0 : c_rs + 1, last_rs ? ni : c_i);
+        // one (step, row set): xc = the step's fragments, xnx = the next step's (fetched at the step's first row set, their bias
+        // sums formed behind its last); prev_rs = the row set of the previous consume (whose products are folded here)
+        auto consume = [&](ring_t& slot, v3h8 (&xc)[4], v3h8 (&xnx)[4], auto rs_tag, bool more_steps) {
+            constexpr int rs = decltype(rs_tag)::value;
+            constexpr int prev_rs = (rs + RSC - 1) % RSC;
+            if (rs == 0) load_x(xnx, xp + (more_steps ? NW * 256 : 0));          // the next step's fragments: in flight during this step
+            // the next consume's scale word: the next row set of this step, or set 0 of the next step
+            const uint32_t szw_n = rs + 1 < RSC ? *(const uint32_t*)(sp + (size_t)(rs + 1) * SZB)
+                                                : *(const uint32_t*)(sp + (more_steps ? s_stride : 0u));
             val_t lo, hi;
+            const ring_t wv = slot;
             if (ABL & 4) {
                 lo = v3_zero<MB>() + __builtin_bit_cast(float, wv[0] ^ wv[1]);
                 hi = v3_zero<MB>() + __builtin_bit_cast(float, wv[2] ^ wv[BITS == 3 ? 0 : 3]);
@@ -587,12 +605,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
 #pragma unroll
                         for (int w = 0; w < 4; ++w) bf[j][w] = ext[4 * j + w];
                 }
-                f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
-                f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
-                Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
-                Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
-                if (last_rs) bias_sums(xn, nlo, nhi);      // the NEXT step's sums ride behind this step's last products
-                fold();                                     // the PREVIOUS (step, row set): its MFMAs retired long ago
+                f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
+                f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
+                Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
+                Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
+                if (rs == RSC - 1) bias_sums(xnx, nlo, nhi);    // the NEXT step's sums ride behind this step's last products
+                fold(acc[prev_rs]);                             // the PREVIOUS (step, row set): its MFMAs retired long ago
                 if (BITS == 3) {
                     lo = v3_pick<MB>(Plo) + v3_pick<MB>(Phi);
                     hi = v3_zero<MB>();
@@ -601,60 +619,57 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                     hi = v3_pick<MB>(Phi);
                 }
             }
-            if (ABL & 4) fold();
+            if (ABL & 4) fold(acc[prev_rs]);
             pv_lo = lo; pv_hi = hi; pv_alo = alo; pv_ahi = ahi; pv_szw = szw;
-            pv_f0 = c_rs == 0 ? 1.f : 0.f; pv_f1 = c_rs == 1 ? 1.f : 0.f; pv_f2 = c_rs == 2 ? 1.f : 0.f; pv_f3 = c_rs == 3 ? 1.f : 0.f;
             szw = szw_n;
-            if (last_rs) {
-                c_rs = 0;
-                ++c_i;
+            issue(slot, std::integral_constant<int, (rs + D) % RSC>{});      // the slot's next load: number c + D of the sequence
+            if (rs == RSC - 1) {                                // step done
                 alo = nlo;
                 ahi = nhi;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) xf[w] = xn[w];
-            } else {
-                ++c_rs;
+                if (more_steps) { xp += NW * 256; sp += s_stride; }
             }
         };
-        const int total = RS * nsw;
-        const int nrounds = (total + D - 1) / D;
-        for (int rd = 0; rd + 1 < nrounds; ++rd) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                consume(ring[d]);
-                issue(ring[d]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if ((nrounds - 1) * D + d < total) consume(ring[d]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        fold();                                // the last (step, row set)
+        // The unrolled round: US steps = US * RSC consumes = a whole number of ring turns, an even number of steps.
+        constexpr int US = v3_unroll_steps(D, RSC);
+        static_assert((US * RSC) % D == 0 && US % 2 == 0, "a round must return every ring slot and both fragment sets to their roles");
+        int i = 0;                                              // step counter of the wave
+        auto round = [&](bool guarded) {
+            v3_static_for<0, US>([&](auto u_tag) {
+                constexpr int u = decltype(u_tag)::value;
+                if (!guarded || i + u < nsw) {
+                    const bool more = i + u + 1 < nsw;
+                    v3_static_for<0, RSC>([&](auto rs_tag) {
+                        constexpr int rs = decltype(rs_tag)::value;
+                        constexpr int c = u * RSC + rs;
+                        if constexpr (u % 2 == 0) consume(ring[c % D], xA, xB, rs_tag, more);
+                        else consume(ring[c % D], xB, xA, rs_tag, more);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+            });
+        };
+        for (; i + US <= nsw; i += US) round(false);
+        if (i < nsw) round(true);
+        fold(acc[RSC - 1]);                    // the last (step, row set)
     }
     V3_STAMP(3);
+    if constexpr ((ABL & 32) != 0 && MB == 1) {     // lab: no cross-wave sum, no barrier -- every wave stores its own partial (garbage results)
+        if (kc == 0 && wave == 0) yout[set0 * 16 + nl] = (f16)acc[0];
+        return;
+    }
     if constexpr (MB == 1) {
-        if (kc == 0) {
-            red[(0 * NW + wave) * 16 + nl] = acc0;
-            if (RS > 1) red[(1 * NW + wave) * 16 + nl] = acc1;
-            if (RS > 2) red[(2 * NW + wave) * 16 + nl] = acc2;
-            if (RS > 3) red[(3 * NW + wave) * 16 + nl] = acc3;
-        }
+        if (kc == 0)
+            v3_static_for<0, RSC>([&](auto r) { red[(decltype(r)::value * NW + wave) * 16 + nl] = acc[r]; });
     } else {
         if (kc < 2) {                           // batch rows 4 kc + j
+            v3_static_for<0, RSC>([&](auto r) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* r0 = red + ((size_t)(0 * NW + wave) * 8 + 4 * kc + j) * 16 + nl;
-                r0[0] = acc0[j];
-                if (RS > 1) r0[(size_t)1 * NW * 128] = acc1[j];
-                if (RS > 2) r0[(size_t)2 * NW * 128] = acc2[j];
-                if (RS > 3) r0[(size_t)3 * NW * 128] = acc3[j];
-            }
+                for (int j = 0; j < 4; ++j) red[((size_t)(decltype(r)::value * NW + wave) * 8 + 4 * kc + j) * 16 + nl] = acc[r][j];
+            });
         }
     }
 
-    // ---- 5. combine the waves, finish the norm, fused epilogues
+    // ---- 5. combine the waves, finish the norm, fused epilogues (a short block's last slot is a copy: rs < RS only)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // step 2b's pieces (a wave without ring steps never waited)
     __syncthreads();
     V3_STAMP(5);

@@ -36,35 +36,39 @@ int gemv_v3_blocks(int nsets) {
 // What the v3 kernel takes: whole 128-k steps, the checkpoint's r = 128 (or no outlier slice), group 128 or per-channel.
 bool gemv_v3_ok(int K, int G, int n_out) { return K % 128 == 0 && K >= 128 && (n_out == 0 || (n_out == 128 && K > 128)) && (G == 128 || G == K); }
 
-template <int NW, int D, bool OUTL, int BITS>
-static hipError_t launch_dm(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
+// Instantiations (8 waves per block; the 16-wave form of round 2 lost to it on every launch kind once the step loop had its row
+// sets at compile time, profiles/r03_gemv_lab.txt): ring depth 2 for every RSC, 4 for RSC <= 2, 6 for RSC >= 3.
+template <int D, bool OUTL, int BITS, int RSC>
+static hipError_t launch_dmr(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
     auto go = [&](auto kern) -> hipError_t {
         if (smem > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(V3_NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
     if constexpr (D == 2 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches, ring depth 2
-        if (a.m > 1) return go(gemv_v3_kernel<NW, 2, OUTL, V3_MODE_PLAIN, 0, 4, 2>);
+        if (a.m > 1) return go(gemv_v3_kernel<V3_NW, 2, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC>);
     }
-    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR, 0, BITS>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN, 0, BITS>);
+    if (a.m > 1) return hipErrorInvalidValue;
+    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<V3_NW, D, OUTL, V3_MODE_PAIR, 0, BITS, 1, RSC>) : go(gemv_v3_kernel<V3_NW, D, OUTL, V3_MODE_PLAIN, 0, BITS, 1, RSC>);
 }
 
-template <int NW, bool OUTL, int BITS>
+template <bool OUTL, int BITS>
 static hipError_t launch_d(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
-    if (depth == 2 || a.m > 1) return launch_dm<NW, 2, OUTL, BITS>(a, mode, nblk, smem, st);
-    if constexpr (NW == 8 && BITS == 4) {      // 16-wave blocks are capped at 128 VGPRs: depth 6 would spill (and has too few steps)
-        if (depth == 6) return launch_dm<NW, 6, OUTL, BITS>(a, mode, nblk, smem, st);
+    switch (a.rs_cap) {           // row sets per block: a compile-time constant of the kernel
+        case 1: return depth >= 4 ? launch_dmr<4, OUTL, BITS, 1>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 1>(a, mode, nblk, smem, st);
+        case 2: return depth >= 4 ? launch_dmr<4, OUTL, BITS, 2>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 2>(a, mode, nblk, smem, st);
+        case 3: return depth >= 4 ? launch_dmr<6, OUTL, BITS, 3>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 3>(a, mode, nblk, smem, st);
+        case 4: return depth >= 4 ? launch_dmr<6, OUTL, BITS, 4>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 4>(a, mode, nblk, smem, st);
     }
-    return launch_dm<NW, 4, OUTL, BITS>(a, mode, nblk, smem, st);
+    return hipErrorInvalidValue;
 }
 
 template <int BITS>
-static hipError_t launch_b(const V3Args& a, int mode, int nblk, size_t smem, int nw, int depth, hipStream_t st) {
-    if (nw == 16) return a.g.n_out > 0 ? launch_d<16, true, BITS>(a, mode, nblk, smem, depth, st) : launch_d<16, false, BITS>(a, mode, nblk, smem, depth, st);
-    return a.g.n_out > 0 ? launch_d<8, true, BITS>(a, mode, nblk, smem, depth, st) : launch_d<8, false, BITS>(a, mode, nblk, smem, depth, st);
+static hipError_t launch_b(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
+    return a.g.n_out > 0 ? launch_d<true, BITS>(a, mode, nblk, smem, depth, st) : launch_d<false, BITS>(a, mode, nblk, smem, depth, st);
 }
 
 static int env_int(const char* name) {
@@ -81,13 +85,7 @@ static bool gemv_v3_plan(V3Args& a, int& nw, size_t& smem) {
     a.sets_q = a.g.nsets / nblk;
     a.sets_r = a.g.nsets % nblk;
     if (a.m < 1) a.m = 1;
-    // one block per CU (<= 256 blocks): 16 waves per block, so that every SIMD still interleaves 4 instruction streams
-    static const int f_nw = env_int("QEFT_GEMV_NW");      // lab override
-    // measured (tools/gemv_v3_lab.hip, profiles/r02_gemv_v3_lab.txt, and A/B runs of the whole decode step): 16 waves where a
-    // CU holds one block and a wave still has several steps (q|k|v 8.3 vs 9.0 us, down_proj 8.0 vs 8.9); o_proj (2 steps
-    // per wave at 16) keeps 8 waves; two blocks per CU (gate|up) run best at 8 waves.
-    const int steps16 = ceil_div(a.g.nfull, 16) * a.rs_cap;
-    nw = f_nw == 8 || f_nw == 16 ? f_nw : (nblk <= 256 && steps16 >= 4 ? 16 : 8);
+    nw = V3_NW;
     a.nw = nw;
     smem = v3_lds(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.m, nw, a.xn_gamma != nullptr && a.szp != nullptr, a.szp == nullptr, a.ids != nullptr).total;
     return smem <= 160 * 1024 && nblk < 65536;       // (nblk, sets_r share dwords with rs_cap, sets_q)
@@ -110,13 +108,16 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     if (a.m > V3_MAX_M || !gemv_v3_plan(a, nw, smem)) return hipErrorInvalidValue;
     if (a.m > 1 && (mode != V3_MODE_PLAIN || a.bits == 3 || a.residual || a.ssq_in || a.xn_gamma)) return hipErrorInvalidValue;
     if (!a.szp && (a.xn_gamma || !a.scales || !a.zeros)) return hipErrorInvalidValue;     // (the zeros pointer uses xn_gamma's slot)
-    static const int f_d = env_int("QEFT_GEMV_DEPTH");     // lab override
-    // Ring depth 2 everywhere: gate|up 12.9 vs 14.3 us at depth 4 (16.6 at 6: registers), o_proj 4.72 vs 5.08 with the
-    // preloaded prologue, the 3-bit stream likewise
-    const int depth = f_d == 2 || f_d == 4 || f_d == 6 ? f_d : 2;
+    static const int f_d = env_int("QEFT_GEMV_DEPTH");     // lab override: 2, or 4 (= the deep form of the block's RSC: 4 or 6 loads)
+    // Ring depth (tools/gemv_v3_lab.hip, interleaved timing, profiles/r03_gemv_lab.txt): where a CU holds ONE block and a wave has
+    // at least 8 loads to make, 4 loads in flight per wave (6 with three or four row sets per block: two whole steps) --
+    // q|k|v 7.06 (6) / 7.44 (4) / 7.69 us (2), down_proj 7.18 (4) / 7.59 (2); short launches (o_proj: 4 loads per wave) and
+    // two blocks per CU (gate|up) keep 2: 4.58 vs 4.78, 10.97 vs 11.07 / 11.50.
+    const int loads_per_wave = ceil_div(a.g.nfull, V3_NW) * a.rs_cap;
+    const int depth = f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 && a.m <= 1 ? 4 : 2);
     const bool w3 = a.bits == 3;
     g_last_variant = a.m > 1 ? "gemv_v3_mb" : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
-    return w3 ? launch_b<3>(a, mode, a.nblk, smem, nw, depth, st) : launch_b<4>(a, mode, a.nblk, smem, nw, depth, st);
+    return w3 ? launch_b<3>(a, mode, a.nblk, smem, depth, st) : launch_b<4>(a, mode, a.nblk, smem, depth, st);
 }
 
 // ---- host-side enumeration of every address the kernel can form for a configuration (no GPU involved).

@@ -1,11 +1,14 @@
 // Lab harness for the v3 decode GEMV (GPU box only): times kernel variants directly, cycling 12 weight sets per kind so that
 // nothing is served from L2 / MALL, on the four launch kinds of a Llama-2-7B decoder layer.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o /tmp/gemv_v3_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DQEFT_LAB -mllvm -amdgpu-kernarg-preload-count=16 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o /tmp/gemv_v3_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <string>
+#include <functional>
+#include <algorithm>
 #include "gemv_v3.h"
 
 namespace qeft { thread_local const char* g_last_variant = ""; }
@@ -54,14 +57,33 @@ static float time_launches(int reps, int L, F f) {
     return ms * 1e3f / (reps * L);
 }
 
+static int qeft_lab_blocks(int nsets) {     // gemv_v3_blocks (gemv_v3.hip)
+    auto cd = [](int a, int b) { return (a + b - 1) / b; };
+    int nblk;
+    if (nsets <= 256) nblk = nsets;
+    else if (nsets < 512) nblk = cd(nsets, 2);
+    else { int k = (nsets + 384) / 768; if (k < 1) k = 1; nblk = 256 * k; }
+    if (cd(nsets, nblk) > V3_MAX_RS) nblk = cd(nsets, V3_MAX_RS);
+    if (nsets >= 512) nblk = cd(nsets, cd(nsets, nblk));
+    return nblk;
+}
 struct Kind { const char* name; int n, k, mode; bool ssq, res; };
+struct Case { std::string label; double bytes; int L; std::function<void(int)> f; std::vector<float> us; };
+static std::vector<Case> g_cases;
 struct Bufs { void *qw, *szp, *ow; };
 
-template <int NW, int D, int MODE, int ABL>
-static void launch(const V3Args& a, int nblk, size_t smem) {
-    auto kern = gemv_v3_kernel<NW, D, true, MODE, ABL>;
+template <int NW, int D, int MODE, int ABL, int RSC>
+static void launch_r(const V3Args& a, int nblk, size_t smem) {
+    auto kern = gemv_v3_kernel<NW, D, true, MODE, ABL, 4, 1, RSC>;
     if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, V3_KERNEL_ARGS(a));
+}
+// the lab's four launch kinds have 3 (q|k|v, gate|up) or 1 (o_proj, down_proj) row sets per block under the product's block rule
+template <int NW, int D, int MODE, int ABL>
+static void launch(const V3Args& a, int nblk, size_t smem) {
+    if (a.rs_cap == 3) launch_r<NW, D, MODE, ABL, 3>(a, nblk, smem);
+    else if (a.rs_cap == 1) launch_r<NW, D, MODE, ABL, 1>(a, nblk, smem);
+    else { printf("    (rs_cap %d not instantiated in the lab)\n", a.rs_cap); }
 }
 
 template <int NW, int D, int ABL>
@@ -77,15 +99,29 @@ static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h3
     a.residual = kd.res ? (const float*)h32 : nullptr; a.y32 = kd.res ? (float*)h32 : nullptr;
     a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
     a.y = (f16*)y;
-    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap);
-    auto f = [&](int l) {
+    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
+    auto f = [a, &B, &kd, nblk, smem](int l) {
         V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
-        if (kd.mode == V3_MODE_PAIR) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); else launch<NW, D, V3_MODE_PLAIN, ABL>(b, nblk, smem);
+        if (kd.mode == V3_MODE_PAIR) { if constexpr (NW == 8) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); }
+        else launch<NW, D, V3_MODE_PLAIN, ABL>(b, nblk, smem);
     };
+    if (kd.mode == V3_MODE_PAIR && NW != 8) return;
     const double bytes = (double)kd.n * (kd.k - 128) / 2 + 2.0 * (kd.k / 128) * kd.n * 2 + (double)kd.n * 128 * 2 + 2 * kd.k + 2 * kd.n;
-    const float us = time_launches(20, (int)B.size(), f);
+    char label[96];
+    snprintf(label, sizeof label, "%-4s NW=%2d D=%d blocks=%4d ABL=%2d", kd.name, NW, D, nblk, ABL);
+    g_cases.push_back(Case{label, bytes, (int)B.size(), f, {}});
+}
+// every registered case timed `rounds` times, the cases interleaved (box-level drift hits all of them alike); min and median
+static void measure_cases(int rounds) {
+    for (int r = 0; r < rounds; ++r)
+        for (auto& c : g_cases) c.us.push_back(time_launches(10, c.L, c.f));
     CK(hipGetLastError());
-    printf("  %-4s NW=%2d D=%d blocks=%4d ABL=%d : %7.2f us  %6.0f GB/s\n", kd.name, NW, D, nblk, ABL, us, bytes / us / 1e3);
+    for (auto& c : g_cases) {
+        std::sort(c.us.begin(), c.us.end());
+        const float mn = c.us.front(), md = c.us[c.us.size() / 2];
+        printf("  %s : min %6.2f  median %6.2f us  %6.0f GB/s (median)\n", c.label.c_str(), mn, md, c.bytes / md / 1e3);
+    }
+    g_cases.clear();
 }
 
 // ABL = 8: time stamps of wave 0 of every block (100 MHz ticks) -> where a launch's time goes
@@ -101,7 +137,7 @@ static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, voi
     a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
     a.y = (f16*)y;
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nblk * 64 * 6));
-    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap);
+    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
     std::vector<long long> h((size_t)nblk * 8 * 6);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int warm = 0; warm < 3; ++warm)
@@ -161,6 +197,7 @@ int main() {
     void* gam = dalloc(4096 * 2, 2, 0x03ff03ffu, 0x3c003c00u);
     void* ssq = dalloc(2048 * 4, 3, 0x007fffffu, 0x3f800000u);
     void* ynorm = dalloc(4096 * 2, 4);
+    const bool full = getenv("LAB_FULL") != nullptr;
     for (const Kind& kd : kinds) {
         std::vector<Bufs> B(L);
         for (auto& b : B) {
@@ -172,21 +209,23 @@ int main() {
         void* y = dalloc(kd.n * 2, 5);
         printf("%s: n=%d k=%d\n", kd.name, kd.n, kd.k);
         const int nsets = kd.n / 16;
-        for (int nblk : {256, 512, 768, 1024}) {
-            if (nblk > nsets) continue;
-            run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nblk);
-            run<16, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nblk);
-        }
-        const int nb = nsets < 512 ? nsets : 256 * ((nsets + 384) / 768);
+        const int nb = qeft_lab_blocks(nsets);
         run<8, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 2, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);      // per-step MFMA bias sums (round 2's form)
+        run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<16, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 1>(kd, B, x, y, h32, gam, ssq, ynorm, nb);     // no bias-sum MFMAs
-        run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);     // no math at all
-        run<16, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        if (nb <= 256) timeline<16, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        timeline<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        timeline<8, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<16, 2, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4, 1>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4, 16>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4, 32>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        measure_cases(7);
+        if (full) {
+            timeline<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+            timeline<8, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        }
         for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
         (void)hipFree(x); (void)hipFree(y);
     }
