@@ -653,6 +653,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
         fold(acc[RSC - 1]);                    // the last (step, row set)
     }
     V3_STAMP(3);
+    // the producer's partial sums of squares: waves 2 and 3 requested them (step 2b) and are the ones that know, through their
+    // own waits, that they have landed -- each sums its piece HERE, in the slack before the final barrier, and leaves one float;
+    // behind the barrier every wave reads two floats instead of reducing 512 (that reduction was ~0.15 us of every q|k|v and
+    // gate|up launch's tail)
+    float* const ssq_part = red + RSC * V3_NW_MAX * 16;              // the 64 spare bytes of the red region
+    if (MB == 1 && ssq_in && (wave == 2 || wave == 3) && (wave - 2) * 256 < ssq_n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        typedef float v3f4 __attribute__((ext_vector_type(4)));
+        const v3f4 p0 = ((const v3f4*)ssql)[(wave - 2) * 64 + lane];
+        const int b0 = (wave - 2) * 256 + 4 * lane;
+        float sp_ = (b0 < ssq_n ? p0[0] : 0.f) + (b0 + 1 < ssq_n ? p0[1] : 0.f) + (b0 + 2 < ssq_n ? p0[2] : 0.f) + (b0 + 3 < ssq_n ? p0[3] : 0.f);
+        sp_ = wave_sum(sp_);
+        if (lane == 0) ssq_part[wave - 2] = sp_;
+    }
     if constexpr ((ABL & 32) != 0 && MB == 1) {     // lab: no cross-wave sum, no barrier -- every wave stores its own partial (garbage results)
         if (kc == 0 && wave == 0) yout[set0 * 16 + nl] = (f16)acc[0];
         return;
@@ -692,16 +706,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
 #pragma unroll
         for (int w = 0; w < NW; ++w) sx += ssql[w];
         rs_norm = __builtin_amdgcn_rsqf(sx * (1.f / (float)G.K) + eps);
-    } else if (ssq_in) {               // every wave sums the (<= 512) partials itself, in a fixed order: no second barrier
-        // two unconditional 16-byte reads per lane (a guarded read is a branch with its own wait); what lies past the array
-        // is dropped by a select, never added.  The wave sum is DPP + readlane (qeft_common.h): with eight guarded reads and
-        // a shuffle butterfly this block cost 0.5 us of every q|k|v and gate|up launch
-        typedef float v3f4 __attribute__((ext_vector_type(4)));
-        const v3f4 p0 = ((const v3f4*)ssql)[lane], p1 = ((const v3f4*)ssql)[lane + 64];     // partials 4 lane .. + 3 and 256 + the same
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += (4 * lane + j < ssq_n ? p0[j] : 0.f) + (256 + 4 * lane + j < ssq_n ? p1[j] : 0.f);
-        s = wave_sum(s);
+    } else if (ssq_in) {               // the two pieces' sums (waves 2 / 3, in front of the barrier)
+        const float s = ssq_part[0] + (ssq_n > 256 ? ssq_part[1] : 0.f);
         rs_norm = __builtin_amdgcn_rsqf(s * (1.f / (float)G.K) + eps);
     }
     auto row_sum = [&](int rs, int n) {
