@@ -57,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--bits", type=int, default=4, choices=[3, 4],
                     help="4: the reference's w4 checkpoint layout (BASELINE configs 1-4, the default); "
                          "3: this build's 3-bit extension layout (config 5)")
+    ap.add_argument("--ckpt", default=None,
+                    help="decode a packed checkpoint in the reference's format (save_model, modelutils.py:248-268; HF key names) "
+                         "instead of the synthetic weights: QuantLlama.from_packed; the shape is read off the tensors")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the PMC child run that fills roofline.traffic")
@@ -370,7 +373,11 @@ def main():
     shape = dataclasses.replace(base, max_seq=max(512, (ctx0 + args.steps + 128 + 8 + 15) // 16 * 16), bits=args.bits)
 
     t_build = time.time()
-    model = QuantLlama(shape, dev, seed=0, fast_init=True)
+    if args.ckpt:
+        model = QuantLlama.from_packed(args.ckpt, dev, max_seq=shape.max_seq)
+        shape = model.shape
+    else:
+        model = QuantLlama(shape, dev, seed=0, fast_init=True)
     eng = DecodeEngine(model, use_graph=not (args.no_graph or shared), tp_group=group)
     eng.greedy = True
     torch.cuda.synchronize(dev)
@@ -516,13 +523,13 @@ def main():
         except Exception as e:
             print(f"[bench] latency protocol failed: {type(e).__name__}: {e}", file=sys.stderr)
         # ---- the reference's entry points for < 8 rows: gemv_4bit_qeft / QuantLinear.forward, m = 1 and 4
-        if args.model == "7b" and args.bits == 4:
+        if args.model == "7b" and args.bits == 4 and not args.ckpt:
             try:
                 extras["boundary_gemv"] = boundary_gemv_records(dev)
             except Exception as e:
                 print(f"[bench] boundary_gemv failed: {type(e).__name__}: {e}", file=sys.stderr)
         # ---- BASELINE configs 3 and 5 at M = 2048 (7B shapes, w4 operands)
-        if args.model == "7b":
+        if args.model == "7b" and not args.ckpt:
             try:
                 del eng
                 fwd_recs, ft_recs = gemm_records(dev)
@@ -550,11 +557,12 @@ def main():
     if rank == 0:
         ms = dt * 1e3 / args.steps
         out = {
-            "metric": "decode tokens/sec, Llama-2-7B w4 g128 r128" if (args.model == "7b" and args.bits == 4)
+            "metric": "decode tokens/sec, Llama-2-7B w4 g128 r128" if (args.model == "7b" and args.bits == 4 and not args.ckpt)
             else f"decode tokens/sec, {shape.name} w{args.bits} g128 r128",
             "value": round(args.steps / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f16",
+            "data": f"packed checkpoint {os.path.basename(args.ckpt)}, random token ids" if args.ckpt else "synthetic",
             "config": {"workload": f"{shape.name} w{args.bits} g{shape.group_size} r{shape.n_out} full decode step, batch 1, "
                                    f"greedy, KV context {ctx0}..{ctx0 + args.steps} tokens ({CONTEXT}-token context + "
                                    f"{args.warmup} warm-up tokens before the timed region)",

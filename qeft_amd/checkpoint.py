@@ -62,6 +62,11 @@ def replace_oweight(model, oweight_state_dict):
         with torch.no_grad():
             layer.oweight.copy_(ow.to(layer.oweight.dtype).to(layer.oweight.device))
         layer.refresh_interleaved()
+    # derived copies of the outlier weights: the prefill operands are rebuilt on the next prompt, a DecodeEngine built before
+    # this call refuses to run (its fuse.py operands are copies too)
+    if getattr(model, "_prefill_ops", None) is not None:
+        model._prefill_ops = None
+    model._oweight_version = getattr(model, "_oweight_version", 0) + 1
 
 
 def save_finetuned(model, base_path, output_dir):

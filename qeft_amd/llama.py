@@ -94,6 +94,14 @@ class _Inner(nn.Module):
     pass
 
 
+class _Norm(nn.Module):
+    """RMSNorm weight holder with HF's key (`...layernorm.weight`, `model.norm.weight`); the arithmetic runs in the kernels."""
+
+    def __init__(self, weight):
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=False)
+
+
 class QuantLlama(nn.Module):
     """Module tree with HF's attribute names; every decoder linear is a packed QuantLinear."""
 
@@ -107,8 +115,7 @@ class QuantLlama(nn.Module):
         self.model = _Inner()
         self.model.embed_tokens = nn.Embedding(s.vocab, s.hidden, dtype=torch.float16, device=device)
         self.model.embed_tokens.weight.data = (torch.randn(s.vocab, s.hidden, generator=gen) * 0.5).half().to(device)
-        self.model.norm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device),
-                                       requires_grad=False)
+        self.model.norm = _Norm((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device))
         self.lm_head = nn.Linear(s.hidden, s.vocab, bias=False, dtype=torch.float16, device=device)
         self.lm_head.weight.data = (torch.randn(s.vocab, s.hidden, generator=gen) * 0.02).half().to(device)
         layers = []
@@ -129,8 +136,8 @@ class QuantLlama(nn.Module):
             L.mlp.gate_proj = synthetic_quantlinear(pre + "mlp.gate_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 4, device, fast_init=fast_init, bits=s.bits)
             L.mlp.up_proj = synthetic_quantlinear(pre + "mlp.up_proj", s.hidden, s.inter, s.n_out, s.group_size, sd + 5, device, fast_init=fast_init, bits=s.bits)
             L.mlp.down_proj = synthetic_quantlinear(pre + "mlp.down_proj", s.inter, s.hidden, s.n_out, s.group_size, sd + 6, device, fast_init=fast_init, bits=s.bits)
-            L.input_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
-            L.post_attention_layernorm = nn.Parameter((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device), requires_grad=False)
+            L.input_layernorm = _Norm((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device))
+            L.post_attention_layernorm = _Norm((1.0 + 0.1 * torch.randn(s.hidden, generator=gen)).half().to(device))
             layers.append(L)
         self.model.layers = nn.ModuleList(layers)
         for prm in self.parameters():
@@ -140,6 +147,82 @@ class QuantLlama(nn.Module):
         ang = torch.arange(s.max_seq, dtype=torch.float64)[:, None] * inv[None, :]
         self.register_buffer("rope_cos", ang.cos().float().to(device), persistent=False)
         self.register_buffer("rope_sin", ang.sin().float().to(device), persistent=False)
+
+    # ------------------------------------------------------------------ packed checkpoint -> model
+    @classmethod
+    def from_packed(cls, checkpoint_path, device="cuda:0", max_seq=512, rms_eps=1e-5, rope_theta=10000.0, name=None):
+        """A packed checkpoint in the reference's on-disk format (save_model, qeft/utils/modelutils.py:248-268) as a QuantLlama
+        the DecodeEngine / prefill / eval_nll run on -- the counterpart of load_owqmodel (modelutils.py:147-183) feeding the
+        reference's decode benchmark (qeft/main.py:310-371, 510-553).  The state dict carries HF's LlamaForCausalLM keys
+        (`model.embed_tokens.weight`, `model.layers.i.self_attn.q_proj.qweight` ..., `model.layers.i.input_layernorm.weight`,
+        `model.norm.weight`, `lm_head.weight`); the shape is read off the tensors (head_dim 128: Llama-2 7B / 13B; HF hub
+        loading and config.json are out of scope, so rms_eps / rope_theta / max_seq are arguments).  A fine-tuned delta
+        (`{oweight_state_dict, base_path}`, save_wctmodel :270-284) loads its base first and replaces the outlier slices."""
+        from argparse import Namespace  # noqa: F401  (the pickle holds argparse.Namespace objects)
+        from .checkpoint import replace_oweight
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        if "base_path" in ckpt:
+            base = ckpt["base_path"]
+            if not os.path.isabs(base) and not os.path.exists(base):
+                base = os.path.join(os.path.dirname(os.path.abspath(checkpoint_path)), base)
+            model = cls.from_packed(base, device, max_seq, rms_eps, rope_theta, name)
+            replace_oweight(model, ckpt["oweight_state_dict"])
+            return model
+        assert ckpt.get("packing", False), "not a packed checkpoint"
+        sd, infos = ckpt["model_state_dict"], ckpt["quantinfos"]
+        vocab, hidden = sd["model.embed_tokens.weight"].shape
+        n_layers = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("model.layers."))
+        info0 = infos["model.layers.0.self_attn.q_proj"]
+        kv = sd["model.layers.0.self_attn.k_proj.scales"].shape[1]
+        inter = sd["model.layers.0.mlp.gate_proj.scales"].shape[1]
+        assert hidden % 128 == 0 and kv % 128 == 0, "the decode attention kernel is built for head_dim 128"
+        gs = info0.group_size if info0.group_size and info0.group_size > 0 else hidden
+        shape = LlamaShape(hidden, inter, n_layers, hidden // 128, kv // 128, vocab, max_seq, rms_eps, rope_theta,
+                           n_out=int(info0.n_out), group_size=int(gs), name=name or os.path.basename(checkpoint_path),
+                           bits=int(info0.bits))
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.shape = shape
+        self.model = _Inner()
+        self.model.embed_tokens = nn.Embedding(vocab, hidden, dtype=torch.float16)
+        self.model.norm = _Norm(torch.empty(hidden, dtype=torch.float16))
+        self.lm_head = nn.Linear(hidden, vocab, bias=False, dtype=torch.float16)
+        layers = []
+        for li in range(n_layers):
+            L = _Layer()
+            L.self_attn, L.mlp = _Attn(), _Mlp()
+            for grp, mod, names in (("self_attn", L.self_attn, ("q_proj", "k_proj", "v_proj", "o_proj")),
+                                    ("mlp", L.mlp, ("gate_proj", "up_proj", "down_proj"))):
+                for nm in names:
+                    full = f"model.layers.{li}.{grp}.{nm}"
+                    qi = infos[full]
+                    n_rows = sd[full + ".scales"].shape[1]
+                    k_cols = hidden if nm != "down_proj" else inter
+                    g = qi.group_size if qi.group_size and qi.group_size > 0 else -1
+                    setattr(mod, nm, QuantLinear(int(qi.bits), k_cols, n_rows, (full + ".bias") in sd, torch.float16, int(qi.n_out),
+                                                 g, bool(getattr(qi, "reorder", True)), full))
+            L.input_layernorm = _Norm(torch.empty(hidden, dtype=torch.float16))
+            L.post_attention_layernorm = _Norm(torch.empty(hidden, dtype=torch.float16))
+            layers.append(L)
+        self.model.layers = nn.ModuleList(layers)
+        # reorder_ids is registered by set_kernel(); a checkpoint saved after set_kernel() carries it already
+        missing, unexpected = self.load_state_dict({k: v for k, v in sd.items() if not k.endswith("reorder_ids")}, strict=False)
+        missing = [k for k in missing if not k.endswith(("rope_cos", "rope_sin"))]
+        assert not missing, f"checkpoint lacks {missing[:4]} ..."
+        self.unexpected_keys = list(unexpected)      # e.g. rotary inv_freq buffers of an HF export: not used here
+        self.to(device)
+        for L in self.model.layers:
+            for mod in (L.self_attn.q_proj, L.self_attn.k_proj, L.self_attn.v_proj, L.self_attn.o_proj, L.mlp.gate_proj,
+                        L.mlp.up_proj, L.mlp.down_proj):
+                mod.set_kernel()
+        for prm in self.parameters():
+            prm.requires_grad_(False)
+        half = shape.head_dim // 2
+        inv = 1.0 / (rope_theta ** (torch.arange(0, half, dtype=torch.float64) / half))
+        ang = torch.arange(max_seq, dtype=torch.float64)[:, None] * inv[None, :]
+        self.register_buffer("rope_cos", ang.cos().float().to(device), persistent=False)
+        self.register_buffer("rope_sin", ang.sin().float().to(device), persistent=False)
+        return self
 
     # ------------------------------------------------------------------ dense fp32 reference
     @torch.no_grad()
@@ -177,7 +260,7 @@ class QuantLlama(nn.Module):
 
         mask = torch.full((T, T), float("-inf"), device=h.device).triu(1)
         for L, d in zip(self.model.layers, dense):
-            x = rms(h, L.input_layernorm)
+            x = rms(h, L.input_layernorm.weight)
             q = rope((x @ d["q_proj"].T).view(T, s.n_heads, 128))
             k = rope((x @ d["k_proj"].T).view(T, s.n_kv_heads, 128))
             v = (x @ d["v_proj"].T).view(T, s.n_kv_heads, 128)
@@ -187,10 +270,10 @@ class QuantLlama(nn.Module):
             a = torch.einsum("hts,shd->thd", att.softmax(-1), v).reshape(T, s.hidden)
             a = a[:, L.self_attn.o_proj.reorder_ids] if hasattr(L.self_attn.o_proj, "reorder_ids") else a
             h = h + a @ d["o_proj"].T
-            x = rms(h, L.post_attention_layernorm)
+            x = rms(h, L.post_attention_layernorm.weight)
             act = torch.nn.functional.silu(x @ d["gate_proj"].T) * (x @ d["up_proj"].T)
             h = h + act @ d["down_proj"].T
-        return rms(h, self.model.norm) @ self.lm_head.weight.float().T
+        return rms(h, self.model.norm.weight) @ self.lm_head.weight.float().T
 
 
 def _rmsnorm(x, gamma, eps):
@@ -260,9 +343,9 @@ def prefill(model: "QuantLlama", tokens, engine=None):
     for li, L in enumerate(model.model.layers):
         at, mlp = L.self_attn, L.mlp
         if delta is None:
-            x = _rmsnorm(h, L.input_layernorm, s.rms_eps)
+            x = _rmsnorm(h, L.input_layernorm.weight, s.rms_eps)
         else:
-            h, x = _add_rmsnorm(h, delta, L.input_layernorm, s.rms_eps)
+            h, x = _add_rmsnorm(h, delta, L.input_layernorm.weight, s.rms_eps)
         fo = fused[li] if fused is not None else {}
         if "qkv" in fo:
             # q|k|v as one GEMM (N = 3 x 4096: 768 tiles of 256 x 128 = three whole rounds of the chip); q, k, v are views of
@@ -285,7 +368,7 @@ def prefill(model: "QuantLlama", tokens, engine=None):
         a = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], kk.transpose(0, 1)[None],
                                                              vv.transpose(0, 1)[None], is_causal=True)[0]    # [H, T, 128]
         a = a.transpose(0, 1).reshape(T, s.hidden).contiguous()
-        h, x = _add_rmsnorm(h, at.o_proj(a), L.post_attention_layernorm, s.rms_eps)     # o_proj gathers its own column order
+        h, x = _add_rmsnorm(h, at.o_proj(a), L.post_attention_layernorm.weight, s.rms_eps)     # o_proj gathers its own column order
         if "gu" in fo and qeft_cuda.gemm_gateup_supported(T, fo["gu"]):
             act = qeft_cuda.gemm_4bit_gateup(x, fo["gu"])             # gate|up as one GEMM, SiLU(gate) * up its epilogue
         else:
@@ -293,7 +376,7 @@ def prefill(model: "QuantLlama", tokens, engine=None):
         delta = mlp.down_proj(act)
     if engine is not None:
         engine.set_position(T)
-    _, hn = _add_rmsnorm(h, delta, model.model.norm, s.rms_eps)
+    _, hn = _add_rmsnorm(h, delta, model.model.norm.weight, s.rms_eps)
     return torch.matmul(hn, model.lm_head.weight.t())
 
 
@@ -324,6 +407,9 @@ class DecodeEngine:
         dev = model.lm_head.weight.device
         self.dev = dev
         self.lib = _lib.lib()
+        # the engine streams COPIES of the outlier weights (fuse.py operands): checkpoint.replace_oweight bumps this counter
+        # and step() / run() then refuse to run on the stale copies
+        self._ow_version = getattr(model, "_oweight_version", 0)
         self.tp_group = tp_group
         self.bits = getattr(s, "bits", 4)
         # tp_group: a torch.distributed group (RCCL), or any object with .world, .rank and .all_gather(out, inp) -- the
@@ -575,7 +661,7 @@ class DecodeEngine:
             lin, pk = self.lin[li], self.packs[li]
             # input_layernorm is fused into the q|k|v launch (x is normalised while it is staged)
             qw, sc, sz, ow, ys, ns, szp = pk["qkv"]
-            ck(group_qkv(h.data_ptr(), L.input_layernorm.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
+            ck(group_qkv(h.data_ptr(), L.input_layernorm.weight.data_ptr(), s.rms_eps, 3, qw, sc, sz, ow, None, szp, ys, ns,
                          s.hidden, g, no, st))
             if not linears_only:
                 if tp:      # local heads only: q/k/v slices straight from the grouped GEMV, natural output order
@@ -615,7 +701,7 @@ class DecodeEngine:
             else:
                 ck(fused_o(self.att.data_ptr(), o, ow_o, h.data_ptr(), szp_o, h.data_ptr(), s.hidden, s.hidden))
             qw, sc, sz, ow, ys, ns, szp = pk["gu"]
-            ck(group_gu(h.data_ptr(), L.post_attention_layernorm.data_ptr(), s.rms_eps, 2, qw, sc, sz, ow, None, szp,
+            ck(group_gu(h.data_ptr(), L.post_attention_layernorm.weight.data_ptr(), s.rms_eps, 2, qw, sc, sz, ow, None, szp,
                         ys, ns, s.hidden, g, no, st))
             if tp:
                 if not linears_only:
@@ -639,7 +725,7 @@ class DecodeEngine:
         if linears_only:
             return
         # an even number of buffer swaps per token: the result is back in hbuf[0]
-        ck(lib.qeft_rmsnorm(h.data_ptr(), None, self.m.model.norm.data_ptr(), None, self.hn.data_ptr(), 1,
+        ck(lib.qeft_rmsnorm(h.data_ptr(), None, self.m.model.norm.weight.data_ptr(), None, self.hn.data_ptr(), 1,
                             s.hidden, s.rms_eps, st))
         torch.matmul(self.hn, self.m.lm_head.weight.t(), out=self.logits)
         ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
@@ -651,10 +737,10 @@ class DecodeEngine:
         w = self.m.lm_head.weight
         if s.hidden in (512, 1024, 2048, 4096, 5120, 8192) and w.dtype == torch.float16 and w.is_contiguous() \
                 and os.environ.get("QEFT_LM_HEAD_TORCH") != "1":
-            ck(lib.qeft_lm_head_f16(h32, self.m.model.norm.data_ptr(), w.data_ptr(), self.logits.data_ptr(), s.hidden, s.vocab,
+            ck(lib.qeft_lm_head_f16(h32, self.m.model.norm.weight.data_ptr(), w.data_ptr(), self.logits.data_ptr(), s.hidden, s.vocab,
                                     s.rms_eps, st))
         else:
-            ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.data_ptr(), self.hn.data_ptr(), 1, s.hidden, s.rms_eps, st))
+            ck(lib.qeft_rmsnorm_f32(h32, self.m.model.norm.weight.data_ptr(), self.hn.data_ptr(), 1, s.hidden, s.rms_eps, st))
             torch.matmul(self.hn, w.t(), out=self.logits)
         ck(lib.qeft_token_end(self.logits.data_ptr(), self.tok.data_ptr(), self.pos.data_ptr(), s.vocab,
                               1 if self.greedy else 0, st))
@@ -683,7 +769,7 @@ class DecodeEngine:
         if not linears_only:
             ck(lib.qeft_token_begin_norm(self.m.model.embed_tokens.weight.data_ptr(), self.tok.data_ptr(),
                                          self.rope_tab.data_ptr(), self.pos.data_ptr(), h32, self.rope_row.data_ptr(),
-                                         layers[0].input_layernorm.data_ptr(), xn, ssq, s.hidden, s.vocab, s.max_seq, st))
+                                         layers[0].input_layernorm.weight.data_ptr(), xn, ssq, s.hidden, s.vocab, s.max_seq, st))
         n_ssq = self.n_ssq_tb
         for li, L in enumerate(layers):
             pk = self.v3ops[li]
@@ -696,10 +782,10 @@ class DecodeEngine:
                                              self.att.data_ptr(),
                                              self.attn_ws.data_ptr() if self.attn_ws is not None else None,
                                              self.attn_split, s.n_heads, s.n_kv_heads, s.max_seq, st))
-            ck(pick("o")(pk["o"], self.att.data_ptr(), h32, residual=h32, gamma_out=L.post_attention_layernorm.data_ptr()))
+            ck(pick("o")(pk["o"], self.att.data_ptr(), h32, residual=h32, gamma_out=L.post_attention_layernorm.weight.data_ptr()))
             n_ssq = self.n_ssq_lin
             ck(pick("gu")(pk["gu"], xn, self.act.data_ptr(), mode=1, ssq_in=ssq, n_ssq=n_ssq))
-            nxt = layers[li + 1].input_layernorm.data_ptr() if li + 1 < len(layers) else None
+            nxt = layers[li + 1].input_layernorm.weight.data_ptr() if li + 1 < len(layers) else None
             ck(pick("d")(pk["d"], self.act.data_ptr(), h32, residual=h32, gamma_out=nxt))
         if linears_only:
             return
@@ -734,12 +820,12 @@ class DecodeEngine:
         if not linears_only:
             ck(lib.qeft_token_begin_norm(self.m.model.embed_tokens.weight.data_ptr(), self.tok.data_ptr(),
                                          self.rope_tab.data_ptr(), self.pos.data_ptr(), cur.data_ptr(), self.rope_row.data_ptr(),
-                                         layers[0].input_layernorm.data_ptr(), self.xn.data_ptr(), self.ssq.data_ptr(), s.hidden,
+                                         layers[0].input_layernorm.weight.data_ptr(), self.xn.data_ptr(), self.ssq.data_ptr(), s.hidden,
                                          s.vocab, s.max_seq, st))
         qp = self.qkv_loc.data_ptr()
         for li, L in enumerate(layers):
             pk = self.tp3ops[li]
-            ck(pick("qkv", hnorm)(pk["qkv"], cur, L.input_layernorm, qp))
+            ck(pick("qkv", hnorm)(pk["qkv"], cur, L.input_layernorm.weight, qp))
             if not linears_only:
                 ck(lib.qeft_rope_attn_decode(qp, qp + self.hs * 2, qp + (self.hs + self.kvs) * 2,
                                              self.rope_row.data_ptr(), self.rope_row.data_ptr() + 64 * 4, 1,
@@ -751,7 +837,7 @@ class DecodeEngine:
             if not linears_only:
                 self._all_reduce(oth)
             cur, oth = oth, cur
-            ck(pick("gu", hnorm)(pk["gu"], cur, L.post_attention_layernorm, pk["x_d"].data_ptr() + pk["lead_d"] * 2, mode=1))
+            ck(pick("gu", hnorm)(pk["gu"], cur, L.post_attention_layernorm.weight, pk["x_d"].data_ptr() + pk["lead_d"] * 2, mode=1))
             ck(pick("d", partial)(pk["d"], pk["x_d"].data_ptr(), cur, oth))
             if not linears_only:
                 self._all_reduce(oth)
@@ -792,11 +878,17 @@ class DecodeEngine:
             if (sp, bool(self.greedy)) not in self.graphs:
                 self.capture(split=sp)
 
+    def _check_fresh(self):
+        if getattr(self.m, "_oweight_version", 0) != self._ow_version:
+            raise RuntimeError("the model's outlier weights were replaced (checkpoint.replace_oweight) after this DecodeEngine "
+                               "derived its operands from them: build a new DecodeEngine")
+
     def step(self):
         """Run one token: consumes self.tok at position self.pos, leaves logits (and, if greedy, the next token)."""
         if self.host_pos >= self.m.shape.max_seq:
             # the device side would skip the attention (stale output) and keep counting: refuse instead
             raise RuntimeError(f"KV cache full: position {self.host_pos} >= max_seq {self.m.shape.max_seq}")
+        self._check_fresh()
         sp = self._split_for(self.host_pos)
         if self.use_graph:
             g = self.graphs.get((sp, bool(self.greedy)))
@@ -816,6 +908,7 @@ class DecodeEngine:
         consecutive tokens need nothing from the host, and one replay per 8 tokens saves 7 of 8 inter-replay gaps (about
         1 % of a 7B token).  logits hold the last token's values."""
         assert self.greedy, "run() feeds every token's argmax to the next: greedy decoding only"
+        self._check_fresh()
         multi_ok = self.use_graph and os.environ.get("QEFT_MULTI_TOKEN_GRAPH") != "0"
         while n_tokens > 0:
             p, m = self.host_pos, self.MULTI

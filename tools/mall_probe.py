@@ -13,7 +13,7 @@ eng = DecodeEngine(model, use_graph=False)
 s = shape
 g, no, eps = s.group_size, s.n_out, s.rms_eps
 xn, ssq, h32 = eng.xn.data_ptr(), eng.ssq.data_ptr(), eng.h32.data_ptr()
-gam = model.model.layers[0].post_attention_layernorm.data_ptr()
+gam = model.model.layers[0].post_attention_layernorm.weight.data_ptr()
 
 def launch(kind, op, st):
     def lin(x, y, mode=0, residual=None, ssq_in=None, n_ssq=0, gamma_out=None):
