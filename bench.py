@@ -333,6 +333,43 @@ def boundary_gemv_records(dev, sets=8, reps=20):
                     "bytes = algorithmic bytes of the call (SURVEY 8d) with m rows of x and y"}
 
 
+def model_13b_record(dev, steps=128, warmup=64):
+    """model_13b: BASELINE config 4's model (Llama-2-13B shapes, w4 g128 r128) on ONE GPU with the headline protocol
+    (64-token context, `warmup` untimed tokens, `steps` timed graph-replayed tokens) and the GEMV launches' rate -- the
+    single-GPU point of the row-sharded curve; compact on purpose."""
+    import dataclasses
+    import torch
+    from qeft_amd.llama import LLAMA2_13B, DecodeEngine, QuantLlama
+    ctx0 = CONTEXT + warmup
+    shape = dataclasses.replace(LLAMA2_13B, max_seq=512)
+    model = QuantLlama(shape, dev, seed=0, fast_init=True)
+    eng = DecodeEngine(model, use_graph=True)
+    eng.greedy = True
+    eng.capture()
+    eng.precapture(ctx0 + steps + 1)
+    eng.reset()
+    eng.tok.fill_(1)
+    for _ in range(ctx0):
+        eng.step()
+    eng.run(eng.MULTI)
+    eng.set_position(ctx0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    eng.run(steps)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    g2 = eng.capture(linears_only=True)
+    launches = 4 * shape.n_layers
+    us = _event_time_us(g2.replay, 20, dev) / launches
+    nbytes = eng.weight_bytes_per_token() / launches
+    rec = {"tokens_per_s": round(steps / dt, 2), "ms_per_step": round(dt * 1e3 / steps, 4), "steps": steps,
+           "gemv_us_per_launch": round(us, 3), "gemv_bytes_per_launch": int(nbytes), "gemv_GB/s": round(nbytes / us / 1e3, 1),
+           "gemv_frac_of_8TB/s": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "workload": f"{shape.name} w4 g128 r128, batch 1, one GPU"}
+    del eng, g2, model
+    torch.cuda.empty_cache()
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -553,6 +590,13 @@ def main():
                                            "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44); w3_expand_us: the 3 -> 4-bit expansion a 3-bit layer adds (once per step: the expanded copy is kept while training)"}
             except Exception as e:
                 print(f"[bench] GEMM sub-records failed: {type(e).__name__}: {e}", file=sys.stderr)
+            # ---- BASELINE config 4's model on one GPU
+            try:
+                model = None
+                torch.cuda.empty_cache()
+                extras["model_13b"] = model_13b_record(dev)
+            except Exception as e:
+                print(f"[bench] model_13b failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     if rank == 0:
         ms = dt * 1e3 / args.steps

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import qeft_oracle as O
-from util import REL_TOL, layer_to_torch, rel_err
+from util import REL_TOL, elem_err_ok, layer_to_torch, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -47,6 +47,7 @@ def test_gemm_forward_m2048(n, k):
     y = y.cpu().numpy()
     assert y.shape == (M, n)
     assert rel_err(y[:, rows], yref) < REL_TOL
+    assert elem_err_ok(y[:, rows], yref)          # element-wise: an error confined to small outputs does not hide behind the max norm
     # every M tile and every N tile carries data: no all-zero 128 x 128 block anywhere in the output
     blocks = np.abs(y.astype(np.float32)).reshape(M // 128, 128, n // 128, 128).max(axis=(1, 3))
     assert (blocks > 0).all()
@@ -73,6 +74,7 @@ def test_gemm_dx_and_grad_oweight_m2048(n, k):
     dx = dx.cpu().numpy()
     assert dx.shape == (M, k)
     assert rel_err(dx[:, cols], dx_ref) < REL_TOL
+    assert elem_err_ok(dx[:, cols], dx_ref)
     dow_ref = dy.astype(np.float64).T @ x[:, k - R:].astype(np.float64)
     assert rel_err(dow.cpu().numpy(), dow_ref) < REL_TOL
 

@@ -7,14 +7,15 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 NLL_TOL = 1e-3
-LOGIT_TOL = 2e-2    # max |dlogit| / max |logit|: fp16 residual stream over 32 layers vs fp32
+LOGIT_TOL = 1e-2    # max |dlogit| / max |logit| of the decode engine (fp32 residual stream, fp16 activations; observed 6e-3)
+PREFILL_LOGIT_TOL = 1e-2   # the prefill pass keeps an fp16 residual stream over the 32 layers (observed 6.1e-3 at 2048 tokens)
 
 
 @pytest.fixture(scope="module")
 def model7b():
     import dataclasses
     from qeft_amd.llama import LLAMA2_7B, QuantLlama
-    shape = dataclasses.replace(LLAMA2_7B, max_seq=512)
+    shape = dataclasses.replace(LLAMA2_7B, max_seq=2048)
     model = QuantLlama(shape, DEV, seed=0, fast_init=True)
     dense = model.dense_weights()          # fp32, ~26 GB: fine on a 288 GB part
     yield model, dense
@@ -73,3 +74,41 @@ def test_engine_7b_crosses_position_256(model7b):
     # the positions around and past the switch on their own: logits and argmax (a mean NLL over 22 tokens is noise-limited:
     # single-token |dNLL| is ~ the logit error, ~5e-3 of max|logit|)
     _compare(got[250:], ref[250:], tokens[250:], nll=False)
+
+
+def test_prefill_7b_shape(model7b, monkeypatch):
+    """BASELINE config 3 composed at full size: a 2048-token prompt through prefill() -- the launches the bench's
+    prefill_2048.whole_model number is made of (q|k|v as one operand with N = 12288, gate|up interleaved in blocks of 64 with the
+    SiLU epilogue, rope_rows on strided rows, the 256 x 128 GEMM tier) -- against the dense fp32 model, every position.
+    The variants the GEMM launches took are recorded and asserted (main.py:264-305, eval_ppl, is the reference's counterpart)."""
+    from qeft_amd import _lib, llama
+    from qeft_amd.llama import prefill
+    model, dense = model7b
+    seen = set()
+    for fn in ("gemm_4bit_qeft", "gemm_4bit_gateup"):
+        orig = getattr(llama.qeft_cuda, fn)
+
+        def wrapped(*a, _orig=orig, **k):
+            out = _orig(*a, **k)
+            seen.add(_lib.last_variant())
+            return out
+        monkeypatch.setattr(llama.qeft_cuda, fn, wrapped)
+    T = 2048
+    tokens = torch.randint(0, model.shape.vocab, (T,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    got = prefill(model, tokens).float()
+    torch.cuda.synchronize()
+    assert seen == {"gemm_v3_256x128", "gemm_v3_256x128+silu_pair"}, seen
+    ref = model.forward_dense_reference(tokens, dense)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item() / scale
+    # 64 sampled positions, printed: where along the prompt the error sits
+    pos = torch.linspace(0, T - 1, 64).long()
+    per = ((got[pos] - ref[pos]).abs().max(-1).values / scale)
+    print(f"[7b prefill] T={T} max|dlogit|/max|logit| = {err:.3e} (sampled positions: median {per.median().item():.2e}, max {per.max().item():.2e})")
+    assert err < PREFILL_LOGIT_TOL, err
+    top2 = ref.topk(2, dim=-1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2 * PREFILL_LOGIT_TOL * scale
+    assert torch.equal(got.argmax(-1)[sure], ref.argmax(-1)[sure])
+    import torch.nn.functional as F
+    d = F.cross_entropy(got[:-1], tokens[1:], reduction="none") - F.cross_entropy(ref[:-1], tokens[1:], reduction="none")
+    assert abs(d.mean().item()) <= 2e-3, d.mean().item()        # teacher-forced NLL over 2047 tokens
