@@ -426,15 +426,23 @@ def main():
         return
 
     graph_ok = eng.use_graph
+    graph_capture_error = None
     if graph_ok:
         try:
             eng.capture()
             eng.precapture(ctx0 + args.steps + 1)     # one graph per attention split the run will reach
         except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
+            graph_capture_error = f"{type(e).__name__}: {e}"[:300]
             if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+                print(f"[bench] graph capture failed ({graph_capture_error}); running eager", file=sys.stderr)
             eng.use_graph, eng.graph, eng.graphs, graph_ok = False, None, {}, False
             torch.cuda.synchronize(dev)
+    if world > 1:      # one rank falling back to eager while the others replay graphs would desynchronise the collectives
+        flag = torch.tensor([0 if graph_ok else 1], device=dev if not shared else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and graph_ok:
+            eng.use_graph, eng.graph, eng.graphs, graph_ok = False, None, {}, False
+            graph_capture_error = "another rank failed to capture its graph: eager on every rank"
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -530,6 +538,56 @@ def main():
         if rank == 0:
             print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
 
+    multi = None
+    if group is not None:
+        # ---- diagnostics of the FIRST multi-GPU runs: who took part, what one collective costs, every rank's rate
+        try:
+            multi = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                     "graph_capture_error": graph_capture_error}
+            names = [None] * world
+            dist.all_gather_object(names, f"rank {rank}: cuda:{dev_index} {torch.cuda.get_device_name(dev)}")
+            multi["devices"] = names
+            # the layer's collective alone: an fp32 all-reduce of `hidden` floats (16 KB for 7B), 64 of them per replay
+            buf = torch.zeros(shape.hidden, dtype=torch.float32, device=dev)
+            red = buf if not shared else buf.cpu()
+            n_coll = 64
+
+            def coll():
+                for _ in range(n_coll):
+                    dist.all_reduce(red)
+            coll()
+            torch.cuda.synchronize(dev)
+            how = "eager"
+            run_coll = coll
+            if not shared:
+                try:
+                    gcoll = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gcoll):
+                        coll()
+                    run_coll, how = gcoll.replay, "hipgraph"
+                except Exception as e:
+                    multi["collective_capture_error"] = f"{type(e).__name__}: {e}"[:200]
+                    torch.cuda.synchronize(dev)
+            barrier()
+            t_c = _event_time_us(run_coll, 10, dev, warm_ms=5.0) / n_coll if not shared else None
+            if shared:
+                t1 = time.perf_counter()
+                coll()
+                t_c = (time.perf_counter() - t1) * 1e6 / n_coll
+            tt = torch.tensor([t_c], dtype=torch.float64, device=dev if not shared else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            multi["collective_us"] = {"all_reduce_fp32_bytes": shape.hidden * 4, "us": round(float(tt.item()), 2), "how": how,
+                                      "per_token": 2 * shape.n_layers if getattr(eng, "tp3", False) else 4 * shape.n_layers}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, {"rank": rank, "gemv_GB/s": roof["achieved"] if roof else None,
+                                              "gemv_frac": roof["frac"] if roof else None,
+                                              "gemv_us_per_launch": roof["us_per_launch"] if roof else None,
+                                              "weight_bytes_per_token": int(eng.weight_bytes_per_token())})
+            multi["per_rank_roofline"] = per_rank
+        except Exception as e:
+            multi = dict(multi or {}, error=f"{type(e).__name__}: {e}"[:300])
+            if rank == 0:
+                print(f"[bench] multi-GPU diagnostics failed: {type(e).__name__}: {e}", file=sys.stderr)
     tp3 = bool(getattr(eng, "tp3", False))      # (the extras below free the engine)
     extras = {}
     if world == 1 and not args.no_extras:
@@ -619,6 +677,10 @@ def main():
                        if group is not None else "single GPU",
                        "build_s": round(t_build, 1), "last_token": last_tok},
         }
+        if graph_capture_error:
+            out["graph_capture_error"] = graph_capture_error
+        if multi:
+            out["multi_gpu"] = multi
         if steady:
             out["steady_128"] = steady
         if roof:

@@ -53,7 +53,8 @@ extern const void* const kSiluPair64;
 bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
-                          void* workspace = nullptr, size_t workspace_bytes = 0, const void* silu_gate = nullptr);
+                          void* workspace = nullptr, size_t workspace_bytes = 0, const void* silu_gate = nullptr,
+                          bool* fused_epilogue = nullptr);
 int gemm_w4_split(int M, int N, int K, int n_out);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace = nullptr,
@@ -215,7 +216,9 @@ int qeft_gemv_w4_qeft(const void* x, const void* qweight, const void* scales, co
 
 static int gemm_impl(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                      const void* oweight, const void* bias, void* y, int m, int n, int k, int group_size, int n_out,
-                     qeft_stream_t stream, void* workspace, size_t workspace_bytes, const void* silu_gate = nullptr) {
+                     qeft_stream_t stream, void* workspace, size_t workspace_bytes, const void* silu_gate = nullptr,
+                     bool* fused_epilogue = nullptr) {
+    if (fused_epilogue) *fused_epilogue = false;
     if (m < 1) return QEFT_ERR_SHAPE;
     if (!oweight) n_out = 0;
     if (int e = check_common(n, k, group_size, n_out)) return e;
@@ -244,7 +247,7 @@ static int gemm_impl(const void* x, const void* qweight, const void* scales, con
         if (e != hipErrorNotSupported) return finish(e);
     }
     return finish(qeft::gemm_w4_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out,
-                                       (hipStream_t)stream, workspace, workspace_bytes, silu_gate));
+                                       (hipStream_t)stream, workspace, workspace_bytes, silu_gate, fused_epilogue));
 }
 
 int qeft_gemm_w4(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
@@ -259,9 +262,10 @@ int qeft_gemm_w4_silu_mul(const void* x, const void* qweight, const void* scales
     if (!gate) return QEFT_ERR_NULL;
     if (n % 8 != 0 || (long long)m * n > 0x7fffffffLL) return QEFT_ERR_SHAPE;
     if (!aligned16(gate) || !aligned16(y)) return QEFT_ERR_ALIGN;
+    bool fused = false;       // reported by the launch itself (the variant string is diagnostic only)
     const int e = gemm_impl(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out, stream, nullptr, 0,
-                            gate);
-    if (e != QEFT_OK || strstr(qeft::g_last_variant, "+silu")) return e;
+                            gate, &fused);
+    if (e != QEFT_OK || fused) return e;
     // a tier without the fused epilogue: the product is in y, finish in place
     return finish(qeft::silu_mul_launch(gate, y, y, m * n, (hipStream_t)stream));
 }

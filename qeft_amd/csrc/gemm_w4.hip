@@ -827,21 +827,25 @@ extern const void* const kSiluPair64 = (const void*)(uintptr_t)1;
 
 // shapes the paired gate|up launch takes (n2 = both linears' rows): the 256-row kernel's domain, whole 128-column tiles
 bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out) {
-    return M >= 1 && n2 % 128 == 0 && K / BK >= G3_BST && K % BK == 0 && n_out % 64 == 0 && (G & (G - 1)) == 0 && G >= 64 &&
+    return M >= 1 && n2 % 128 == 0 && K / BK >= G3_BST && K % BK == 0 && n_out % 64 == 0 && (K - n_out) / BK >= 2 &&
+           (G & (G - 1)) == 0 && G >= 64 &&
            (size_t)M * K * 2 < (1ull << 32) && (size_t)(n2 / 4) * K * 2 < (1ull << 32);
 }
 
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
-                          void* workspace, size_t workspace_bytes, const void* silu_gate) {
+                          void* workspace, size_t workspace_bytes, const void* silu_gate, bool* fused_epilogue) {
     const bool outl = ow && n_out > 0;
+    if (fused_epilogue) *fused_epilogue = false;      // set by the tier that forms silu(gate) * y in its own epilogue
     // 256 x 128 tiles, one wave per SIMD (gemm_w4_kernel_v3), when they give (nearly) every CU a block: the M >= 2048 tier
     // of a prefill / fine-tune step.  QEFT_GEMM_V3 = 0 / 1 forces the choice (A/B).
     {
         static const int force_v3 = getenv("QEFT_GEMM_V3") ? atoi(getenv("QEFT_GEMM_V3")) : -1;
         const int mb = (M + G3_BM - 1) / G3_BM, nb = (N + G3_BN - 1) / G3_BN;
-        const bool ok3 = K / BK >= G3_BST && K % BK == 0 && (!outl || n_out % 64 == 0) && (G & (G - 1)) == 0 && G >= 64 &&
-                         N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
+        // (at least two INT4 k-tiles: with exactly one, the odd-count prologue of the k loop would dequantise k-tile 1 -- an fp16
+        //  outlier tile whose weight slot was never staged -- as INT4; such shapes keep the 128-row kernels)
+        const bool ok3 = K / BK >= G3_BST && K % BK == 0 && (!outl || n_out % 64 == 0) && (K - (outl ? n_out : 0)) / BK >= 2 &&
+                         (G & (G - 1)) == 0 && G >= 64 && N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
         if (silu_gate == kSiluPair64 && !(ok3 && N % 128 == 0)) return hipErrorNotSupported;     // capi checks gemm_w4_pair64_ok first
         if (ok3 && (silu_gate == kSiluPair64 || force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024)) &&
             (!silu_gate || N % 8 == 0)) {
@@ -854,10 +858,12 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                 return hipGetLastError();
             };
             if (silu_gate == kSiluPair64) {
+                if (fused_epilogue) *fused_epilogue = true;
                 g_last_variant = "gemm_v3_256x128+silu_pair";
                 return outl ? go3(gemm_w4_kernel_v3<true, 0, 2>) : go3(gemm_w4_kernel_v3<false, 0, 2>);
             }
             if (silu_gate) {
+                if (fused_epilogue) *fused_epilogue = true;
                 g_last_variant = "gemm_v3_256x128+silu";
                 return outl ? go3(gemm_w4_kernel_v3<true, 0, 1>) : go3(gemm_w4_kernel_v3<false, 0, 1>);
             }

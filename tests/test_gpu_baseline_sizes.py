@@ -151,3 +151,30 @@ def test_dx_large_m_tile_edges(m, n, k, r, g):
     w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None, g)
     ref = dy.astype(np.float64) @ w.astype(np.float64)
     assert rel_err(dx.cpu().numpy(), ref) < REL_TOL
+
+
+def test_gemm_one_int4_ktile_keeps_the_128_row_kernels():
+    """K - n_out = 64: exactly ONE INT4 k-tile.  The 256-row tier's k loop needs two (its odd-count prologue dequantises k-tile
+    1, here an fp16 outlier tile), so the launcher must leave this shape -- otherwise inside the tier's domain (M = 1024,
+    56 column tiles) -- to the 128-row kernels; full output vs the oracle (round-2 advisory)."""
+    from qeft_amd import _lib, qeft_cuda
+    m, n, k, r, g = 1024, 7168, 512, 448, 64
+    bufs = O.make_layer(n, k, r, g, seed=17, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=3)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"], t["bias"])
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant.startswith("gemm_v2"), variant
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], bufs["bias"], g).astype(np.float64)
+    assert rel_err(y.cpu().numpy(), yref) < REL_TOL
+    assert elem_err_ok(y.cpu().numpy(), yref)
+    # two INT4 k-tiles: back on the 256-row tier
+    bufs2 = O.make_layer(n, k, 384, g, seed=18)
+    t2 = layer_to_torch(bufs2, DEV)
+    x2 = O.make_activation(m, k, 384, seed=4)
+    y2 = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x2).to(DEV), t2["qweight"], t2["scales"], t2["scaled_zeros"], t2["oweight"])
+    assert _lib.last_variant() == "gemm_v3_256x128"
+    torch.cuda.synchronize()
+    yref2 = O.quant_linear(x2, bufs2["qweight"], bufs2["scales"], bufs2["scaled_zeros"], bufs2["oweight"], None, g).astype(np.float64)
+    assert rel_err(y2.cpu().numpy(), yref2) < REL_TOL
