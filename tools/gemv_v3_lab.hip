@@ -211,16 +211,10 @@ int main() {
         const int nsets = kd.n / 16;
         const int nb = qeft_lab_blocks(nsets);
         run<8, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 2, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);      // per-step MFMA bias sums (round 2's form)
         run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<16, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<16, 2, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 1>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 4, 16>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 32>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         measure_cases(7);
         if (full) {
             timeline<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
