@@ -333,6 +333,39 @@ def boundary_gemv_records(dev, sets=8, reps=20):
                     "bytes = algorithmic bytes of the call (SURVEY 8d) with m rows of x and y"}
 
 
+def mid_m_records(dev, ms=(64, 512, 1024), layers=4, reps=25):
+    """prefill_mid_m: the forward GEMM below the M = 2048 tier -- M = 64 (benchmark.py's 64-token prompt), 512 and 1024 (short
+    prompts, fine-tune batches) on the three 7B shapes; us, TFLOP/s, fraction of the dense fp16 MFMA peak, variant."""
+    import torch
+    from qeft_amd import _lib, qeft_cuda
+    recs, r, g = [], 128, 128
+    for (n, k) in SHAPES_7B:
+        ws = []
+        for _ in range(layers):
+            qw = torch.randint(-32768, 32767, (n // 4, k), dtype=torch.int16, device=dev)
+            sc = (torch.rand(k // g, n, device=dev) * 0.004 + 0.001).half()
+            sz = (-(torch.rand(k // g, n, device=dev) * 8 + 4) * sc.float()).half()
+            ow = (torch.randn(n, r, device=dev) * 0.02).half()
+            ws.append((qw, sc, sz, ow))
+        rec = {"shape": f"{n}x{k}"}
+        for m in ms:
+            x = torch.randn(m, k, device=dev).half()
+            var = {}
+
+            def fwd():
+                for qw, sc, sz, ow in ws:
+                    qeft_cuda.gemm_4bit_qeft(x, qw, sc, sz, ow)
+                var["v"] = _lib.last_variant()
+            t = _event_time_us(fwd, reps, dev) / layers
+            fl = 2.0 * m * n * k
+            rec[f"M{m}"] = {"us": round(t, 1), "TFLOPs": round(fl / t / 1e6, 1), "frac_of_peak": round(fl / t / 1e6 / MFMA_PEAK_TFLOPS, 4),
+                            "variant": var["v"]}
+        recs.append(rec)
+        del ws
+        torch.cuda.empty_cache()
+    return recs
+
+
 def model_13b_record(dev, steps=128, warmup=64):
     """model_13b: BASELINE config 4's model (Llama-2-13B shapes, w4 g128 r128) on ONE GPU with the headline protocol
     (64-token context, `warmup` untimed tokens, `steps` timed graph-replayed tokens) and the GEMV launches' rate -- the
@@ -644,6 +677,8 @@ def main():
                                       "linears_TFLOP": round(lin_flops / 1e12, 2),
                                       "note": "2048-token prompt through every packed linear (GEMM path), torch fused SDPA attention"}
                 extras["prefill_2048"] = pre
+                extras["prefill_mid_m"] = {"per_shape": mid_m_records(dev), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                                           "note": "forward GEMM (fused outlier slice) below the M = 2048 tier, 4 weight sets cycled"}
                 extras["finetune_step"] = {"M": 2048, "per_shape": ft_recs,
                                            "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44); w3_expand_us: the 3 -> 4-bit expansion a 3-bit layer adds (once per step: the expanded copy is kept while training)"}
             except Exception as e:

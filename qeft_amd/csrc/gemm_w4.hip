@@ -451,6 +451,21 @@ __device__ __forceinline__ void g3_dma_a8(const void* sbase, const uint32_t (&vo
           "v"(voff[6]), "v"(voff[7])
         : "memory", "scc");
 }
+// four pieces (the 128-row tile's loader waves)
+__device__ __forceinline__ void g3_dma_a4(const void* sbase, const uint32_t (&voff)[4], uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(sbase), "s"(lds_dst), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3])
+        : "memory", "scc");
+}
+__device__ __forceinline__ void g3_dma_a(const void* sbase, const uint32_t (&voff)[8], uint32_t lds_dst) { g3_dma_a8(sbase, voff, lds_dst); }
+__device__ __forceinline__ void g3_dma_a(const void* sbase, const uint32_t (&voff)[4], uint32_t lds_dst) { g3_dma_a4(sbase, voff, lds_dst); }
 __device__ __forceinline__ void g3_dma16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
@@ -469,7 +484,10 @@ __device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32
 // EPI 2: W holds gate and up interleaved in blocks of 64 rows (fuse.pair64_gemm_operand), so that columns 0..63 of a block's
 // tile are gate and 64..127 the same columns of up: y [M][N/2] = silu(tile[:, :64]) * tile[:, 64:], one launch for both
 // linears, no gate round trip through HBM.
-template <bool OUTL, int ABL = 0, int EPI = 0>
+// MT: 32-row m-tiles per block tile: 8 (256 x 128, the M >= 1024 tier) or 4 (128 x 128, round 3: the tier between the small-M
+// kernels and 224 tiles of 256 rows -- M = 512 .. 1024 of a short prompt or a fine-tune batch; same roles, rings and waits, the
+// activation stage is 16 KB instead of 32 and a loader wave stages 4 pieces of it instead of 8).
+template <bool OUTL, int ABL = 0, int EPI = 0, int MT = 8>
 __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
@@ -479,6 +497,11 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // waves 4..7 load (wave 4 + l: activation pieces 8 l .. 8 l + 7, the packed weights of compute wave l, scales / zeros).
     // An LDS-DMA instruction holds its wave for 100-200 cycles at issue; in the compute waves' own stream (first version)
     // that stalled the matrix pipe 8 times per k-tile.  Loader waves absorb it in the shadow of their SIMD partner's MFMAs.
+    static_assert(MT == 8 || MT == 4, "256- or 128-row block tiles");
+    static_assert(MT == 8 || EPI == 0, "the fused activation epilogues exist for the 256-row tile only");
+    constexpr int BMR = 32 * MT, AP = MT;                     // rows of the tile; activation pieces (1 KB) per loader wave and stage
+    constexpr int A_B = BMR * BK * 2;                         // bytes of an activation stage
+    constexpr int BOFF = G3_ST * A_B, SOFF = BOFF + G3_BST * G3_B;      // [4 x A][6 x B 4 KB][6 x scales 512 B]
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const long long t_entry = ABL == 6 ? wall_clock64() : 0;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
@@ -487,7 +510,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through consecutive tiles of one row block
     const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
     const int c = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
-    const int bm0 = (c / NB) * G3_BM, bn0 = (c % NB) * G3_BN;
+    const int bm0 = (c / NB) * BMR, bn0 = (c % NB) * G3_BN;
     const int ktiles = K / BK;
     const int kq = K - (OUTL ? n_out : 0);
     const int qtiles = kq / BK;            // INT4 k-tiles [0, qtiles); fp16 outlier k-tiles [qtiles, ktiles)
@@ -498,10 +521,10 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const int l = wave - 4;
         const int gshift = 31 - __builtin_clz(G);
         // A piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7)
-        uint32_t a_off[8];
+        uint32_t a_off[AP];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (l * 8 + i) * 8 + (lane >> 3);
+        for (int i = 0; i < AP; ++i) {
+            const int row = (l * AP + i) * 8 + (lane >> 3);
             const int grow = min(bm0 + row, M - 1);
             a_off[i] = (uint32_t)grow * (uint32_t)K * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
         }
@@ -513,13 +536,13 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const uint8_t* const sz_base = (const uint8_t*)(l == 0 ? scales : zeros);
         auto stage_a = [&](int t) {            // 8 DMA instructions
             if (ABL == 1 || ABL >= 3) return;
-            g3_dma_a8((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * G3_A + (uint32_t)l * 8192u);
+            g3_dma_a((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * A_B + (uint32_t)l * (AP * 1024u));
         };
         auto stage_b = [&](int t, int slot) {  // 2 (l < 2) or 1 DMA instructions
             if (ABL == 1 || ABL >= 3) return;
-            g3_dma16(qw + (size_t)t * 128, b_off, lds0 + G3_BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
+            g3_dma16(qw + (size_t)t * 128, b_off, lds0 + BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
             if (l < 2)
-                g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + G3_SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
+                g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
         };
         // In-order completion: at the top of iteration t the activations of k-tile t + 1 (the LAST thing iteration t - 2
         // issued) must have landed; younger than them is exactly what iteration t - 1 issued: [weights / scales of k-tile
@@ -527,9 +550,9 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         // older still (iteration t - 4).  Towards the end the refills stop (weights first).
         auto wait_prev = [&](bool prev_a, bool prev_b) {
             if (!prev_a) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (!prev_b) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (l < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (!prev_b) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");
+            else if (l < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + 2) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + 1) : "memory");
         };
 #pragma unroll
         for (int t = 0; t < LEAD_B; ++t)
@@ -538,13 +561,13 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         for (int t = 0; t < LEAD; ++t)
             if (t < ktiles) stage_a(t);
         // activations of k-tile 0 landed <=> at most the 16 youngest pieces (k-tiles 1, 2) outstanding
-        if (ktiles >= LEAD) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (ktiles >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int slot_f = LEAD_B % G3_BST;
         for (int t = 0; t < ktiles; ++t) {         // INT4 and fp16 outlier k-tiles alike (the latter have no weight pieces)
             if (t == 0) {
-                if (ktiles >= LEAD) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // k-tile 1: all but k-tile 2's pieces
+                if (ktiles >= LEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");     // k-tile 1: all but k-tile 2's pieces
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 wait_prev((t - 1) + LEAD < ktiles, (t - 1) + LEAD_B < qtiles);
@@ -562,9 +585,9 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     const int nloc = wave * 32 + r;
     const int ncol = min(bn0 + nloc, N - 1);
 
-    f32x16 acc[8];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -572,8 +595,8 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     uint32_t a_rd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_rd[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));
-    const uint32_t b_rd = (uint32_t)(G3_BOFF + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);      // + slot * G3_B
-    const uint32_t s_rd = (uint32_t)(G3_SOFF + nloc * 2);                                          // + slot * G3_S
+    const uint32_t b_rd = (uint32_t)(BOFF + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);         // + slot * G3_B
+    const uint32_t s_rd = (uint32_t)(SOFF + nloc * 2);                                             // + slot * G3_S
 
     // B fragments of a k-tile: k-step j contracts the 8 consecutive k h*32 + 8j .. +7 = pair j of each of the 4 nibble words
     auto dequant_tile = [&](int slot, u32x4 (&bf)[4]) {
@@ -621,8 +644,8 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     auto tile_body = [&](auto tail_tag, int t, int slot_n2, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         if (ABL == 2) return;
-        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * G3_A;
-        const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * G3_A;
+        const uint8_t* st = lds + (size_t)(t & (G3_ST - 1)) * A_B;
+        const uint8_t* sn = lds + (size_t)((t + 1) & (G3_ST - 1)) * A_B;
         const bool has_next = !TAIL || t + 1 < ktiles;
         const u32x4 q = qn;
         const h2 sc = splat(sn_), zc = splat(zn_);
@@ -633,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             for (int j = 0; j < 4; ++j) bn[j] = p[j];
         }
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             u32x4 (&cur)[4] = (mt & 1) ? fb : fa;
             u32x4 (&nxt)[4] = (mt & 1) ? fa : fb;
             if (mt == 0) {                  // behind the first MFMA: everything it waits for (lgkmcnt(0): hipcc does not count
@@ -643,7 +666,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ABL == 5) {
-            } else if (mt < 7) {
+            } else if (mt < MT - 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
             } else if (has_next) {
@@ -657,11 +680,17 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
                                                                 acc[mt], 0, 0, 0);
             if (!TAIL && ABL != 4) {        // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
-                if ((mt & 1) == 0) {
-                    nib8_to_q(q[mt >> 1], qx);
-                } else {
+                if constexpr (MT == 8) {
+                    if ((mt & 1) == 0) {
+                        nib8_to_q(q[mt >> 1], qx);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bn[j][mt >> 1] = as_u32(__builtin_elementwise_fma(qx[j], sc, zc));
+                        for (int j = 0; j < 4; ++j) bn[j][mt >> 1] = as_u32(__builtin_elementwise_fma(qx[j], sc, zc));
+                    }
+                } else {                    // four phases per k-tile: a whole word per phase
+                    nib8_to_q(q[mt], qx);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bn[j][mt] = as_u32(__builtin_elementwise_fma(qx[j], sc, zc));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -735,7 +764,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const float bv = bias ? (float)bias[ncol] : 0.f;
         uint8_t* const col = lds + nloc * 2;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 *(f16*)(col + (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * G3_YP) = (f16)(acc[mt][e] + bv);
@@ -745,8 +774,8 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     if (EPI == 0) {
         const int ch = lane & 15, n0 = bn0 + ch * 8;
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int row = wave * 64 + i * 4 + (lane >> 4), m = bm0 + row;
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int row = wave * (8 * MT) + i * 4 + (lane >> 4), m = bm0 + row;
             if (m >= M || n0 >= N) continue;
             const u32x4 v = *(const u32x4*)(lds + row * G3_YP + ch * 16);
             f16* dst = y + (size_t)m * N + n0;
@@ -878,6 +907,27 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             if (abl == 6) return go3(gemm_w4_kernel_v3<true, 6>);
 #endif
             return outl ? go3(gemm_w4_kernel_v3<true>) : go3(gemm_w4_kernel_v3<false>);
+        }
+        // The same design with 128-row tiles (round 3) for the sizes between the small-M kernels and that tier -- M = 512 .. 1024
+        // of a short prompt or a fine-tune batch, narrow N at larger M: taken from 112 tiles of 128 x 128 on (measured crossover
+        // against the 128-row kernels below, profiles/r03_gemm_mid_m.txt: 4096 x 4096 at M = 512, 128 tiles: 28.4 vs 34.6 us;
+        // 11008 x 4096 at M = 256, 172 tiles: 30.4 vs 43.6; 64 tiles lose).  QEFT_GEMM_V3M = 0 / 1 forces the choice.
+        {
+            static const int force_m = getenv("QEFT_GEMM_V3M") ? atoi(getenv("QEFT_GEMM_V3M")) : -1;
+            const int mb4 = (M + 127) / 128;
+            if (ok3 && !silu_gate && (force_m == 1 || (force_m != 0 && mb4 * nb >= 112 && M > 128))) {
+                constexpr int SMEM4 = G3_ST * 128 * BK * 2 + G3_BST * G3_B + G3_BST * G3_S;         // 93184 bytes
+                auto go4 = [&](auto kern) -> hipError_t {
+                    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(kern, dim3(mb4 * nb), dim3(512), SMEM4, st, (const f16*)x, (const uint8_t*)qw,
+                                       (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
+                                       (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)nullptr);
+                    return hipGetLastError();
+                };
+                g_last_variant = "gemm_v3_128x128";
+                return outl ? go4(gemm_w4_kernel_v3<true, 0, 0, 4>) : go4(gemm_w4_kernel_v3<false, 0, 0, 4>);
+            }
         }
     }
     // 128 x 256 tiles (8 waves) when they still give every CU a block: always a gain where the 128 x 128 kernel's scale

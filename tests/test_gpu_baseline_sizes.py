@@ -178,3 +178,26 @@ def test_gemm_one_int4_ktile_keeps_the_128_row_kernels():
     torch.cuda.synchronize()
     yref2 = O.quant_linear(x2, bufs2["qweight"], bufs2["scales"], bufs2["scaled_zeros"], bufs2["oweight"], None, g).astype(np.float64)
     assert rel_err(y2.cpu().numpy(), yref2) < REL_TOL
+
+
+@pytest.mark.parametrize("m,n,k,r,g", [(1024, 4096, 4096, 128, 128), (700, 5000, 1024, 64, 64), (513, 8192, 640, 128, 128),
+                                       (1000, 4096, 1536, 0, 256), (960, 3200, 2048, 128, 2048), (130, 7168, 512, 128, 128)])
+def test_gemm_mid_m_tier_128_row_tiles(m, n, k, r, g):
+    """The 128 x 128 form of the loader-wave GEMM (round 3; the reference's tuned tiers for mid-size M: gemm_cuda.cu:952-1004):
+    M = 512 .. 1024 on wide layers -- whole tiles, ragged M and N (N % 128 != 0, M % 128 != 0), group 64 / 256 / per-channel,
+    64 / 0 outlier columns, a K loop barely longer than the rings (10 k-tiles).  Full output vs the oracle, variant asserted."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=m + n + k, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=13)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                 t.get("oweight") if r else None, t["bias"])
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == "gemm_v3_128x128", variant
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None,
+                          bufs["bias"], g).astype(np.float64)
+    y = y.cpu().numpy()
+    assert y.shape == (m, n)
+    assert rel_err(y, yref) < REL_TOL
+    assert elem_err_ok(y, yref)
