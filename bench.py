@@ -255,14 +255,42 @@ def gemm_records(dev, m=2048, layers=4, reps=25):
         fwd_recs.append({"shape": f"{n}x{k}", "us": round(t_f, 1), "TFLOPs": round(flops / t_f / 1e6, 1),
                          "frac_of_peak": round(flops / t_f / 1e6 / MFMA_PEAK_TFLOPS, 4), "variant": variants["fwd"],
                          "hipblaslt_dense_fp16_us": round(t_d, 1), "hipblaslt_dense_fp16_TFLOPs": round(flops / t_d / 1e6, 1)})
-        # BASELINE config 5 names the 3-bit pack: a w3 layer's GEMM / backward run the same kernels on its 3 -> 4-bit expansion
-        # (QuantLinear(bits=3) keeps one expanded copy per layer while training), so its step adds this pass once
-        q3 = torch.randint(-2 ** 31, 2 ** 31 - 1, (n // 16, (k - r) // 128 * 192), dtype=torch.int32, device=dev)
-        q4 = torch.empty(n // 4, k, dtype=torch.int16, device=dev)
-        t_e = _event_time_us(lambda: qeft_cuda.expand_3bit(q3, n, k, r, out=q4), reps, dev)
-        del q3, q4
+        # d(oweight) does not depend on dX: on a second stream beside it (what an autograd engine with two streams, or a fused
+        # backward, gets) -- reported next to the serial sum
+        side = torch.cuda.Stream(dev)
+
+        def dx_dow_overlapped():
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in ws:
+                    qeft_cuda.grad_oweight(dy, x, r)
+            for qw, sc, sz, ow in ws:
+                qeft_cuda.gemm_4bit_dx(dy, qw, sc, sz, ow)
+            cur.wait_stream(side)
+        t_xw = _event_time_us(dx_dow_overlapped, reps, dev) / layers
+        # BASELINE config 5 names the 3-bit pack: the same step on the 3-bit stream itself (round 3: the loader-wave tiers unpack
+        # the 12-byte lane records in registers; no expansion pass)
+        w3 = [(torch.randint(-2 ** 31, 2 ** 31 - 1, (n // 16, (k - r) // 128 * 192), dtype=torch.int32, device=dev), sc, sz, ow)
+              for (_, sc, sz, ow) in ws]
+
+        def fwd3():
+            for q3, sc, sz, ow in w3:
+                qeft_cuda.gemm_3bit_qeft(x, q3, sc, sz, ow)
+            variants["fwd_w3"] = _lib.last_variant()
+
+        def dx3():
+            for q3, sc, sz, ow in w3:
+                qeft_cuda.gemm_3bit_dx(dy, q3, sc, sz, ow, k)
+            variants["dx_w3"] = _lib.last_variant()
+        t_f3 = _event_time_us(fwd3, reps, dev) / layers
+        t_x3 = _event_time_us(dx3, reps, dev) / layers
+        del w3
         ft_recs.append({"shape": f"{n}x{k}", "forward_us": round(t_f, 1), "dx_us": round(t_x, 1), "dow_us": round(t_w, 1),
-                        "step_us": round(t_f + t_x + t_w, 1), "w3_expand_us": round(t_e, 1),
+                        "step_us": round(t_f + t_x + t_w, 1), "dx_dow_overlapped_us": round(t_xw, 1),
+                        "step_overlapped_us": round(t_f + t_xw, 1),
+                        "w3_forward_us": round(t_f3, 1), "w3_dx_us": round(t_x3, 1), "w3_step_us": round(t_f3 + t_x3 + t_w, 1),
+                        "w3_over_w4": round((t_f3 + t_x3 + t_w) / (t_f + t_x + t_w), 4),
                         "dx_TFLOPs": round(flops / t_x / 1e6, 1), "dx_frac_of_peak": round(flops / t_x / 1e6 / MFMA_PEAK_TFLOPS, 4),
                         "step_TFLOPs": round((2 * flops + 2.0 * m * n * r) / (t_f + t_x + t_w) / 1e6, 1),
                         "variants": dict(variants)})
@@ -680,7 +708,7 @@ def main():
                 extras["prefill_mid_m"] = {"per_shape": mid_m_records(dev), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
                                            "note": "forward GEMM (fused outlier slice) below the M = 2048 tier, 4 weight sets cycled"}
                 extras["finetune_step"] = {"M": 2048, "per_shape": ft_recs,
-                                           "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44); w3_expand_us: the 3 -> 4-bit expansion a 3-bit layer adds (once per step: the expanded copy is kept while training)"}
+                                           "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44); dx_dow_overlapped_us: dX with d(oweight) on a second stream; w3_*: the same step of a 3-bit layer on the 3-bit stream (no expansion pass)"}
             except Exception as e:
                 print(f"[bench] GEMM sub-records failed: {type(e).__name__}: {e}", file=sys.stderr)
             # ---- BASELINE config 4's model on one GPU

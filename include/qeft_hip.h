@@ -272,6 +272,19 @@ int qeft_lm_head_f16(const void* h32, const void* gamma, const void* weight, voi
 int qeft_residual_norm(const void* h32, const void* add, const void* gamma, void* h32_out, void* h_norm, float* ssq_out,
                        int hidden, qeft_stream_t stream);
 
+/* GEMM forward / dX of a 3-bit layer ON the 3-bit stream (round 3): the loader-wave tiers (256 x 128 tiles from 224 tiles and
+ * M >= 1024, the forward also 128 x 128 tiles from 112 tiles and M > 128) stage / load the 12-byte lane records and unpack them in
+ * registers -- no 3 -> 4-bit expansion pass.  qeft_gemm_w3[_dx]_supported says whether a shape is taken (k % 128 == 0,
+ * n_out % 128 == 0, group a power of two >= 64 (dX: a multiple of 128), n % 16 == 0 (dX: n % 64 == 0, n >= 256)); other shapes
+ * go through qeft_expand_w3 and the 4-bit entries.  Arguments as qeft_gemm_w4 / qeft_gemm_w4_dx with qweight3 int32
+ * [n/16, ((k - n_out)/128) * 192]. */
+int qeft_gemm_w3_supported(int m, int n, int k, int group_size, int n_out);
+int qeft_gemm_w3(const void* x, const void* qweight3, const void* scales, const void* scaled_zeros, const void* oweight,
+                 const void* bias, void* y, int m, int n, int k, int group_size, int n_out, qeft_stream_t stream);
+int qeft_gemm_w3_dx_supported(int m, int n, int k, int group_size, int n_out);
+int qeft_gemm_w3_dx(const void* dy, const void* qweight3, const void* scales, const void* scaled_zeros, const void* oweight,
+                    void* dx, int m, int n, int k, int group_size, int n_out, qeft_stream_t stream);
+
 /* ---- 3-bit EXTENSION (BASELINE config 5).  The reference cannot pack or run 3 bits (QuantLinear asserts
  * bits == 4, qlinear.py:127; its quantiser can produce them, quant.py:8-10 with maxq = 7), so the layout is this
  * library's own, shaped by the decode GEMV (oracle/qeft_oracle.py: pack_w3 / w3_position):

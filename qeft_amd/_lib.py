@@ -47,6 +47,10 @@ SIGNATURES = {
     "qeft_gemv_w3_group": [_p, _p, ctypes.c_float, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_gemv_w3_silu": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_expand_w3": [_p, _p, _i, _i, _i, _p],
+    "qeft_gemm_w3_supported": [_i, _i, _i, _i, _i],
+    "qeft_gemm_w3": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "qeft_gemm_w3_dx_supported": [_i, _i, _i, _i, _i],
+    "qeft_gemm_w3_dx": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "qeft_attn_workspace_bytes": [_i, _i],
     "qeft_token_begin": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_token_end": [_p, _p, _p, _i, _i, _p],

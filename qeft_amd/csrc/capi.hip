@@ -54,11 +54,13 @@ bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
                           void* workspace = nullptr, size_t workspace_bytes = 0, const void* silu_gate = nullptr,
-                          bool* fused_epilogue = nullptr);
+                          bool* fused_epilogue = nullptr, int bits = 4);
+int gemm_w3_native_tile(int M, int N, int K, int G, int n_out);
+bool gemm_w3_dx_native(int M, int N, int K, int G, int n_out);
 int gemm_w4_split(int M, int N, int K, int n_out);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace = nullptr,
-                             size_t workspace_bytes = 0);
+                             size_t workspace_bytes = 0, int bits = 4);
 int gemm_w4_dx_split(int M, int N, int K);
 hipError_t grad_oweight_launch(const void* dy, const void* x, void* dow, int M, int N, int K, int n_out,
                                hipStream_t st);
@@ -284,6 +286,37 @@ int qeft_gemm_w4_gateup(const void* x, const void* qweight, const void* scales, 
     if (!aligned16(x) || !aligned16(qweight) || !aligned16(y) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
     return finish(qeft::gemm_w4_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n2, k, group_size, n_out,
                                        (hipStream_t)stream, nullptr, 0, qeft::kSiluPair64));
+}
+
+/* ---- 3-bit extension: GEMM forward / dX on the 3-bit stream itself (the loader-wave tiers), no expansion pass */
+int qeft_gemm_w3_supported(int m, int n, int k, int group_size, int n_out) {
+    if (m < 1 || n < 16 || k < 128 || group_size < 1 || n_out < 0) return 0;
+    return qeft::gemm_w3_native_tile(m, n, k, group_size, n_out) != 0;
+}
+
+int qeft_gemm_w3(const void* x, const void* qweight3, const void* scales, const void* scaled_zeros, const void* oweight,
+                 const void* bias, void* y, int m, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    if (!oweight) n_out = 0;
+    if (!qeft_gemm_w3_supported(m, n, k, group_size, n_out)) return QEFT_ERR_SHAPE;
+    if (!x || !qweight3 || !scales || !scaled_zeros || !y) return QEFT_ERR_NULL;
+    if (!aligned16(x) || !aligned16(qweight3) || !aligned16(y) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
+    return finish(qeft::gemm_w4_launch(x, qweight3, scales, scaled_zeros, oweight, bias, y, m, n, k, group_size, n_out,
+                                       (hipStream_t)stream, nullptr, 0, nullptr, nullptr, 3));
+}
+
+int qeft_gemm_w3_dx_supported(int m, int n, int k, int group_size, int n_out) {
+    if (m < 1 || n < 16 || k < 128 || group_size < 1 || n_out < 0) return 0;
+    return qeft::gemm_w3_dx_native(m, n, k, group_size, n_out) ? 1 : 0;
+}
+
+int qeft_gemm_w3_dx(const void* dy, const void* qweight3, const void* scales, const void* scaled_zeros, const void* oweight,
+                    void* dx, int m, int n, int k, int group_size, int n_out, qeft_stream_t stream) {
+    if (!oweight) n_out = 0;
+    if (!qeft_gemm_w3_dx_supported(m, n, k, group_size, n_out)) return QEFT_ERR_SHAPE;
+    if (!dy || !qweight3 || !scales || !scaled_zeros || !dx) return QEFT_ERR_NULL;
+    if (!aligned16(dy) || (reinterpret_cast<uintptr_t>(qweight3) & 3u) || !aligned16(dx) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
+    return finish(qeft::gemm_w4_dx_launch(dy, qweight3, scales, scaled_zeros, oweight, dx, m, n, k, group_size, n_out,
+                                          (hipStream_t)stream, nullptr, 0, 3));
 }
 
 long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {

@@ -487,7 +487,10 @@ __device__ __forceinline__ void g3_dma4(const void* sbase, uint32_t voff, uint32
 // MT: 32-row m-tiles per block tile: 8 (256 x 128, the M >= 1024 tier) or 4 (128 x 128, round 3: the tier between the small-M
 // kernels and 224 tiles of 256 rows -- M = 512 .. 1024 of a short prompt or a fine-tune batch; same roles, rings and waits, the
 // activation stage is 16 KB instead of 32 and a loader wave stages 4 pieces of it instead of 8).
-template <bool OUTL, int ABL = 0, int EPI = 0, int MT = 8>
+// BITS = 3 (round 3): `qw` is the 3-bit EXTENSION layout int32 [N/16][(K - n_out)/128][4 chunks][16 rows][3] (oracle.pack_w3) --
+// the loader waves stage the two 384-byte runs (2 row sets x 2 chunks x 16 rows x 12 B) of a compute wave's 32 columns per
+// k-tile, the compute lanes unpack their 12-byte record (row, chunk) in registers: no 3 -> 4-bit expansion pass.
+template <bool OUTL, int ABL = 0, int EPI = 0, int MT = 8, int BITS = 4>
 __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__ x, const uint8_t* __restrict__ qw,
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
@@ -530,7 +533,10 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         }
         // B: the 1 KB of compute wave l's 32 columns (row groups bn0/4 + 8l ..): lane -> (row group lane/8, 16-byte piece lane%8)
         const int brg = min(bn0 / 4 + l * 8 + (lane >> 3), N / 4 - 1);
-        const uint32_t b_off = (uint32_t)brg * (uint32_t)K * 2u + (uint32_t)(lane & 7) * 16u;
+        // 3 bits: lanes 0..23 the 384 bytes of row set bn0 / 16 + 2 l, lanes 24..47 the next set's (the rest repeat the last piece)
+        const int l3 = min(lane, 47), set3 = min(bn0 / 16 + 2 * l + l3 / 24, N / 16 - 1);
+        const uint32_t b_off = BITS == 3 ? (uint32_t)set3 * (uint32_t)(kq / 128) * 768u + (uint32_t)(l3 % 24) * 16u
+                                         : (uint32_t)brg * (uint32_t)K * 2u + (uint32_t)(lane & 7) * 16u;
         // scales (l == 0) / scaled zeros (l == 1) of the tile's group: 128 columns x 2 B = 64 lanes x 4 B
         const uint32_t s_off = (uint32_t)min(bn0 + 2 * lane, N - 2) * 2u;
         const uint8_t* const sz_base = (const uint8_t*)(l == 0 ? scales : zeros);
@@ -540,7 +546,8 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         };
         auto stage_b = [&](int t, int slot) {  // 2 (l < 2) or 1 DMA instructions
             if (ABL == 1 || ABL >= 3) return;
-            g3_dma16(qw + (size_t)t * 128, b_off, lds0 + BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
+            g3_dma16(qw + (BITS == 3 ? (size_t)(t >> 1) * 768 + (size_t)(t & 1) * 384 : (size_t)t * 128), b_off,
+                     lds0 + BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
             if (l < 2)
                 g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
         };
@@ -595,19 +602,36 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     uint32_t a_rd[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_rd[j] = (uint32_t)(r * 128 + (((h * 4 + j) ^ ((r >> 1) & 7)) << 4));
-    const uint32_t b_rd = (uint32_t)(BOFF + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);         // + slot * G3_B
+    const uint32_t b_rd = BITS == 3 ? (uint32_t)(BOFF + wave * 1024 + (r >> 4) * 384 + h * 192 + (r & 15) * 12)
+                                    : (uint32_t)(BOFF + (nloc >> 2) * 128 + (nloc & 3) * 32 + h * 16);        // + slot * G3_B
     const uint32_t s_rd = (uint32_t)(SOFF + nloc * 2);                                             // + slot * G3_S
 
     // B fragments of a k-tile: k-step j contracts the 8 consecutive k h*32 + 8j .. +7 = pair j of each of the 4 nibble words
+    uint32_t MAGIC3 = 0x64006400u;
+    asm volatile("" : "+v"(MAGIC3));
+    auto read_q = [&](int slot) {              // the lane's packed record of a k-tile: 16 bytes (4 bits) or 12 (3 bits, word 3 unused)
+        if constexpr (BITS == 3) {
+            const uint32_t* p = (const uint32_t*)(lds + b_rd + slot * G3_B);
+            return u32x4{p[0], p[1], p[2], 0u};
+        } else {
+            return *(const u32x4*)(lds + b_rd + slot * G3_B);
+        }
+    };
     auto dequant_tile = [&](int slot, u32x4 (&bf)[4]) {
-        const u32x4 q = *(const u32x4*)(lds + b_rd + slot * G3_B);
+        const u32x4 q = read_q(slot);
         const h2 sc = splat(*(const f16*)(lds + s_rd + slot * G3_S)), zc = splat(*(const f16*)(lds + s_rd + slot * G3_S + 256));
+        if constexpr (BITS == 3) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            h2 wd[4];
-            dequant8(q[w], sc, zc, wd);
+            for (int e = 0; e < 16; ++e)       // fragment j, word w = pair 4 j + w of the chunk (k = h * 32 + 8 j + 2 w, + 1)
+                bf[e >> 2][e & 3] = as_u32(__builtin_elementwise_fma(w3_pair_q(q[0], q[1], q[2], e, MAGIC3), sc, zc));
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j][w] = as_u32(wd[j]);
+            for (int w = 0; w < 4; ++w) {
+                h2 wd[4];
+                dequant8(q[w], sc, zc, wd);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j][w] = as_u32(wd[j]);
+            }
         }
     };
     u32x4 bA[4], bB[4];        // B fragments of the even / odd k-tiles
@@ -637,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     u32x4 qn;
     f16 sn_, zn_;
     auto fetch_b = [&](int slot) {
-        qn = *(const u32x4*)(lds + b_rd + slot * G3_B);
+        qn = read_q(slot);
         sn_ = *(const f16*)(lds + s_rd + slot * G3_S);
         zn_ = *(const f16*)(lds + s_rd + slot * G3_S + 256);
     };
@@ -679,7 +703,14 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             for (int j = mt == 0 ? 1 : 0; j < 4; ++j)
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, cur[j]), __builtin_bit_cast(h8, bc[j]),
                                                                 acc[mt], 0, 0, 0);
-            if (!TAIL && ABL != 4) {        // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
+            if (!TAIL && ABL != 4 && BITS == 3) {       // 16 pairs of k-tile t + 1 over the MT phases
+                constexpr int PP = 16 / MT;
+#pragma unroll
+                for (int i = 0; i < PP; ++i) {
+                    const int e = mt * PP + i;
+                    bn[e >> 2][e & 3] = as_u32(__builtin_elementwise_fma(w3_pair_q(q[0], q[1], q[2], e, MAGIC3), sc, zc));
+                }
+            } else if (!TAIL && ABL != 4) { // word mt / 2 of k-tile t + 1: exact q in the even phase, one rounded FMA per weight in the odd
                 if constexpr (MT == 8) {
                     if ((mt & 1) == 0) {
                         nib8_to_q(q[mt >> 1], qx);
@@ -861,11 +892,40 @@ bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out) {
            (size_t)M * K * 2 < (1ull << 32) && (size_t)(n2 / 4) * K * 2 < (1ull << 32);
 }
 
+// The tiers that read the 3-bit extension layout directly (0: none -- expand first; 8 / 4: the 256- / 128-row loader-wave tile)
+int gemm_w3_native_tile(int M, int N, int K, int G, int n_out) {
+    const int nb = (N + G3_BN - 1) / G3_BN;
+    const bool ok = K % 128 == 0 && n_out % 128 == 0 && n_out < K && (K - n_out) / BK >= 2 && K / BK >= G3_BST && N % 16 == 0 &&
+                    (G & (G - 1)) == 0 && G >= 64 && (size_t)M * K * 2 < (1ull << 32) &&
+                    (size_t)(N / 16) * ((K - n_out) / 128) * 768 < (1ull << 32);
+    if (!ok) return 0;
+    if (((M + G3_BM - 1) / G3_BM) * nb >= 224 && M >= 1024) return 8;
+    if (((M + 127) / 128) * nb >= 112 && M > 128) return 4;
+    return 0;
+}
+
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
-                          void* workspace, size_t workspace_bytes, const void* silu_gate, bool* fused_epilogue) {
+                          void* workspace, size_t workspace_bytes, const void* silu_gate, bool* fused_epilogue, int bits) {
     const bool outl = ow && n_out > 0;
     if (fused_epilogue) *fused_epilogue = false;      // set by the tier that forms silu(gate) * y in its own epilogue
+    if (bits == 3) {
+        const int tile = silu_gate ? 0 : gemm_w3_native_tile(M, N, K, G, outl ? n_out : 0);
+        if (!tile) return hipErrorNotSupported;
+        const int nb = (N + G3_BN - 1) / G3_BN, mbt = (M + 32 * tile - 1) / (32 * tile);
+        const int smem = G3_ST * 32 * tile * BK * 2 + G3_BST * G3_B + G3_BST * G3_S;
+        auto go = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(mbt * nb), dim3(512), smem, st, (const f16*)x, (const uint8_t*)qw, (const f16*)scales,
+                               (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias, (f16*)y, M, N, K, G,
+                               outl ? n_out : 0, nb, (const f16*)nullptr);
+            return hipGetLastError();
+        };
+        g_last_variant = tile == 8 ? "gemm_v3_256x128_w3" : "gemm_v3_128x128_w3";
+        if (tile == 8) return outl ? go(gemm_w4_kernel_v3<true, 0, 0, 8, 3>) : go(gemm_w4_kernel_v3<false, 0, 0, 8, 3>);
+        return outl ? go(gemm_w4_kernel_v3<true, 0, 0, 4, 3>) : go(gemm_w4_kernel_v3<false, 0, 0, 4, 3>);
+    }
     // 256 x 128 tiles, one wave per SIMD (gemm_w4_kernel_v3), when they give (nearly) every CU a block: the M >= 2048 tier
     // of a prefill / fine-tune step.  QEFT_GEMM_V3 = 0 / 1 forces the choice (A/B).
     {
@@ -1278,11 +1338,20 @@ constexpr size_t D3_SMEM = (size_t)D3_WOFF + 2 * D3_W;                  // 16384
 template <int S>
 __device__ __forceinline__ void d3_pload(uint32_t qoff, const void* qb, uint32_t soff, const void* sb, const void* zb);
 template <int S>
+__device__ __forceinline__ void d3_pload3(uint32_t qoff, const void* qb, uint32_t soff, const void* sb, const void* zb);   // 3-bit records: 12 bytes
+template <int S>
 __device__ __forceinline__ void d3_pread(u32x4& q, uint32_t& sv, uint32_t& zv);
 #define D3_RING_SET(S, A0, A1, A2, A3, A4, A5)                                                                                  \
     template <>                                                                                                                 \
     __device__ __forceinline__ void d3_pload<S>(uint32_t qoff, const void* qb, uint32_t soff, const void* sb, const void* zb) { \
         asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, %1\n\tglobal_load_ushort a" #A4 ", %2, %3\n\t"               \
+                     "global_load_ushort a" #A5 ", %2, %4"                                                                      \
+                     :: "v"(qoff), "s"(qb), "v"(soff), "s"(sb), "s"(zb)                                                         \
+                     : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3, "a" #A4, "a" #A5);                                         \
+    }                                                                                                                           \
+    template <>                                                                                                                 \
+    __device__ __forceinline__ void d3_pload3<S>(uint32_t qoff, const void* qb, uint32_t soff, const void* sb, const void* zb) { \
+        asm volatile("global_load_dwordx3 a[" #A0 ":" #A2 "], %0, %1\n\tglobal_load_ushort a" #A4 ", %2, %3\n\t"               \
                      "global_load_ushort a" #A5 ", %2, %4"                                                                      \
                      :: "v"(qoff), "s"(qb), "v"(soff), "s"(sb), "s"(zb)                                                         \
                      : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3, "a" #A4, "a" #A5);                                         \
@@ -1301,6 +1370,9 @@ D3_RING_SET(2, 16, 17, 18, 19, 20, 21)
 D3_RING_SET(3, 24, 25, 26, 27, 28, 29)
 #undef D3_RING_SET
 
+// BITS = 3 (round 3): qw is the 3-bit extension layout; a loader lane owns the 12-byte record (row, 32-k chunk) of its tile
+// position and unpacks it into the same four 16-byte fp16 runs -- the dX of a 3-bit layer without an expansion pass.
+template <int BITS = 4>
 __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
                                                               const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                               const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
@@ -1332,8 +1404,10 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
         };
         // weight role of the lane: row group 4 l + lane/16 of the tile's 16, piece p = lane % 16 of its 256 contiguous bytes
         // = row n & 3 = (p & 7) >> 1, 32-k chunk kc = 2 (p >> 3) + (p & 1) of the 128-k tile
+        // (3 bits: wave l takes row set l of the tile's four, lane = (chunk lane / 16, row lane % 16): 768 contiguous bytes per wave)
         const int rgl = l * 4 + (lane >> 4), pp = lane & 15;
-        const int n_l = rgl * 4 + ((pp & 7) >> 1), n3 = n_l & 3, kc = 2 * (pp >> 3) + (pp & 1);
+        const int n_l = BITS == 3 ? l * 16 + (lane & 15) : rgl * 4 + ((pp & 7) >> 1), n3 = n_l & 3;
+        const int kc = BITS == 3 ? (lane >> 4) : 2 * (pp >> 3) + (pp & 1);
         uint32_t w_dst[4];         // the lane's four 16-byte slots in the fp16 tile (+ buffer offset)
 #pragma unroll
         for (int j = 0; j < 4; ++j) w_dst[j] = (uint32_t)(D3_WOFF + n_l * 256 + (((kc * 4 + j) ^ (n3 << 2) ^ n3) << 4));
@@ -1343,14 +1417,19 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
         };
 
         if (!outl_blk) {
-            const uint32_t q_off = (uint32_t)rgl * (uint32_t)K * 2u + (uint32_t)pp * 16u;
+            const uint32_t set_b3 = (uint32_t)(kq / 128) * 768u;         // bytes of one 16-row set of the 3-bit stream
+            const uint32_t q_off = BITS == 3 ? (uint32_t)l * set_b3 + (uint32_t)lane * 12u : (uint32_t)rgl * (uint32_t)K * 2u + (uint32_t)pp * 16u;
             const uint32_t s_off = (uint32_t)n_l * 2u;
             const size_t grp = (size_t)((kt * D3_BK) / G) * N;
             // ring set S (tile i lives in set i % 4) <- the lane's 16 packed bytes, scale and zero of tile t: 3 vector-memory operations
             auto pload = [&](auto set_tag, int t) {
                 t = min(t, ntiles - 1);            // past the end: a harmless reload, the queue depth stays the same
-                d3_pload<decltype(set_tag)::value>(q_off, qw + (size_t)t * 16 * K * 2 + (size_t)kt * 256, s_off,
-                                                   scales + grp + (size_t)t * D3_BN, zeros + grp + (size_t)t * D3_BN);
+                if constexpr (BITS == 3)
+                    d3_pload3<decltype(set_tag)::value>(q_off, qw + (size_t)t * 4 * set_b3 + (size_t)kt * 768, s_off,
+                                                        scales + grp + (size_t)t * D3_BN, zeros + grp + (size_t)t * D3_BN);
+                else
+                    d3_pload<decltype(set_tag)::value>(q_off, qw + (size_t)t * 16 * K * 2 + (size_t)kt * 256, s_off,
+                                                       scales + grp + (size_t)t * D3_BN, zeros + grp + (size_t)t * D3_BN);
             };
             auto dequant_store = [&](auto set_tag, int buf) {
                 u32x4 q;
@@ -1358,12 +1437,20 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
                 d3_pread<decltype(set_tag)::value>(q, sv, zv);
                 const h2 sc = splat(as_h2(sv)[0]), zc = splat(as_h2(zv)[0]);
                 u32x4 run[4];      // run j = the 8 consecutive k 8j .. 8j + 7 of the chunk
+                if constexpr (BITS == 3) {
+                    uint32_t MAGIC3 = 0x64006400u;
+                    asm volatile("" : "+v"(MAGIC3));
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    h2 wd[4];
-                    dequant8(q[w], sc, zc, wd);
+                    for (int e = 0; e < 16; ++e)
+                        run[e >> 2][e & 3] = as_u32(__builtin_elementwise_fma(w3_pair_q(q[0], q[1], q[2], e, MAGIC3), sc, zc));
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) run[j][w] = as_u32(wd[j]);
+                    for (int w = 0; w < 4; ++w) {
+                        h2 wd[4];
+                        dequant8(q[w], sc, zc, wd);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) run[j][w] = as_u32(wd[j]);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) *(u32x4*)(lds + w_dst[j] + buf * D3_W) = run[j];
@@ -1608,9 +1695,30 @@ int gemm_w4_dx_split(int M, int N, int K) {
     return s < 2 ? 1 : s;
 }
 
+// bits == 3: qw is the 3-bit extension layout; only the loader-wave tier reads it (hipErrorNotSupported otherwise: the caller
+// expands to the 4-bit layout, qeft_expand_w3, and comes back with bits == 4)
+bool gemm_w3_dx_native(int M, int N, int K, int G, int n_out) {
+    const int mb = (M + D3_BM - 1) / D3_BM, kb = K / D3_BK;
+    return K % D3_BK == 0 && n_out % D3_BK == 0 && n_out < K && G % D3_BK == 0 && N % D3_BN == 0 && N >= 4 * D3_BN &&
+           (size_t)M * N * 2 < (1ull << 32) && (size_t)(N / 16) * ((K - n_out) / 128) * 768 < (1ull << 32) &&
+           (size_t)N * n_out * 2 < (1ull << 32) && mb * kb >= 224 && M >= 1024;
+}
+
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace,
-                             size_t workspace_bytes) {
+                             size_t workspace_bytes, int bits) {
+    if (bits == 3) {
+        const bool outl = ow && n_out > 0;
+        if (!gemm_w3_dx_native(M, N, K, G, outl ? n_out : 0)) return hipErrorNotSupported;
+        const int mb = (M + D3_BM - 1) / D3_BM, kb = K / D3_BK;
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_dx_kernel_v3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D3_SMEM);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gemm_w4_dx_kernel_v3<3>, dim3(mb * kb), dim3(512), D3_SMEM, st, (const f16*)dy, (const uint8_t*)qw,
+                           (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (f16*)dx, M, N, K, G,
+                           outl ? n_out : 0, kb);
+        g_last_variant = "dx256_w3";
+        return hipGetLastError();
+    }
     // 256 x 128 tiles with loader waves (gemm_w4_dx_kernel_v3) when they give (nearly) every CU a block: the M >= 2048 tier
     // of a fine-tune step.  QEFT_DX_V3 = 0 / 1 forces the choice (A/B).
     {
@@ -1621,9 +1729,9 @@ hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales,
                          (size_t)M * N * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32) &&
                          (size_t)N * (outl ? n_out : 0) * 2 < (1ull << 32);
         if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * kb >= 224 && M >= 1024))) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_dx_kernel_v3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D3_SMEM);
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_dx_kernel_v3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D3_SMEM);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(gemm_w4_dx_kernel_v3, dim3(mb * kb), dim3(512), D3_SMEM, st, (const f16*)dy, (const uint8_t*)qw,
+            hipLaunchKernelGGL(gemm_w4_dx_kernel_v3<4>, dim3(mb * kb), dim3(512), D3_SMEM, st, (const f16*)dy, (const uint8_t*)qw,
                                (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (f16*)dx, M, N, K, G,
                                outl ? n_out : 0, kb);
             g_last_variant = "dx256";

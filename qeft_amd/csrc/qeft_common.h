@@ -68,6 +68,21 @@ __device__ __forceinline__ void dequant8(uint32_t v, h2 s, h2 z, h2 (&w)[4]) {
     for (int j = 0; j < 4; ++j) w[j] = __builtin_elementwise_fma(q[j], s, z);
 }
 
+// 3-bit EXTENSION layout (oracle.pack_w3 / w3_position): a lane record (row, 32-k chunk) is three words; pair e (k = 2e, 2e + 1 of
+// the chunk, natural order) sits at bits 3 (e % 5) of each half-word of word e / 5 for e < 15, pair 15 in bits 15 / 31 of the
+// three words (bit b of the value in word b).  q[e] = the exact integer pair as fp16 (0x6400 trick, then - 1024).
+__device__ __forceinline__ h2 w3_pair_q(uint32_t w0, uint32_t w1, uint32_t w2, int e, uint32_t MAGIC) {
+    const h2 k1024 = {(f16)1024.f, (f16)1024.f};
+    uint32_t f;
+    if (e < 15) {
+        const uint32_t v = e < 5 ? w0 : e < 10 ? w1 : w2;
+        f = (v >> (3 * (e % 5))) & 0x00070007u;
+    } else {
+        f = ((w0 >> 15) & 0x00010001u) | ((w1 >> 14) & 0x00020002u) | ((w2 >> 13) & 0x00040004u);
+    }
+    return as_h2(f | MAGIC) - k1024;
+}
+
 // Arguments of the decode GEMV (gemv_w4.hip); built by the C ABI (capi.hip).
 struct GemvArgs {
     const f16* x;

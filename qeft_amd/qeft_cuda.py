@@ -290,6 +290,50 @@ def gemv_3bit(x, qweight3, scales, scaled_zeros, oweight_il, bias, residual, m, 
     return out
 
 
+def gemm_3bit_qeft(in_feats, qweight3, scales, zeros, oweights, bias=None):
+    """gemm_4bit_qeft for a 3-bit layer: the loader-wave GEMM tiers read the 3-bit stream directly (qeft_gemm_w3); shapes
+    they do not take are expanded to the 4-bit layout into a buffer of THIS call (no shared scratch) and use the 4-bit entry."""
+    _need(in_feats.is_cuda and in_feats.dtype == torch.float16, "in_feats must be a Half GPU tensor (no CPU fallback)")
+    _need(qweight3.dtype == torch.int32 and qweight3.is_contiguous(), "qweight3 must be a contiguous Int tensor")
+    x = in_feats.contiguous()
+    k = x.shape[-1]
+    n = qweight3.shape[0] * 16
+    m = x.numel() // k
+    n_out = oweights.shape[1] if oweights is not None else 0
+    _need(qweight3.shape[1] == (k - n_out) // 128 * 192, f"qweight3 has {qweight3.shape[1]} columns, expected {(k - n_out) // 128 * 192}")
+    group = k // scales.shape[0]
+    lib = _lib.lib()
+    if m == 0 or not lib.qeft_gemm_w3_supported(m, n, k, group, n_out):
+        return gemm_4bit_qeft(in_feats, expand_3bit(qweight3, n, k, n_out), scales, zeros, oweights, bias)
+    if oweights is not None:
+        _need(oweights.dtype == torch.float16 and oweights.is_contiguous() and oweights.shape[0] == n,
+              "oweights must be a contiguous Half [N, r] tensor")
+    out = torch.empty(*in_feats.shape[:-1], n, dtype=in_feats.dtype, device=in_feats.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.qeft_gemm_w3(x.data_ptr(), qweight3.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                    oweights.data_ptr() if n_out else None, bias.data_ptr() if bias is not None else None,
+                                    out.data_ptr(), m, n, k, group, n_out, _stream(x)))
+    return out
+
+
+def gemm_3bit_dx(grad_out, qweight3, scales, zeros, oweights, k):
+    """gemm_4bit_dx for a 3-bit layer (k: in_features; the 3-bit buffer has no columns for the fp16 slice)."""
+    dy = grad_out.contiguous()
+    n = qweight3.shape[0] * 16
+    m = dy.numel() // n
+    n_out = oweights.shape[1] if oweights is not None else 0
+    group = k // scales.shape[0]
+    lib = _lib.lib()
+    if m == 0 or not lib.qeft_gemm_w3_dx_supported(m, n, k, group, n_out):
+        return gemm_4bit_dx(grad_out, expand_3bit(qweight3, n, k, n_out), scales, zeros, oweights)
+    _need(dy.dtype == torch.float16 and dy.shape[-1] == n, "grad_out must be Half [..., N]")
+    out = torch.empty(*grad_out.shape[:-1], k, dtype=grad_out.dtype, device=grad_out.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.qeft_gemm_w3_dx(dy.data_ptr(), qweight3.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+                                       oweights.data_ptr() if n_out else None, out.data_ptr(), m, n, k, group, n_out, _stream(dy)))
+    return out
+
+
 def expand_3bit(qweight3, n, k, n_out, out=None):
     """3-bit stream -> int16 [n/4, k] in the 4-bit checkpoint layout (for the GEMM / backward / dequant kernels)."""
     _need(qweight3.is_cuda and qweight3.dtype == torch.int32 and qweight3.is_contiguous(),

@@ -101,9 +101,6 @@ def unpack_w3(qweight3):
     return out.reshape(nrs * 16, steps * 128).to(torch.uint8)
 
 
-_W3_SCRATCH = {}   # device -> int16 scratch for the expanded 4-bit view of a 3-bit layer (inference, M > 16)
-
-
 # ----------------------------------------------------------------------------------------------------
 # autograd wrappers (reference QuantMatMulQEFT / QuantMatMul, qlinear.py:13-68)
 # ----------------------------------------------------------------------------------------------------
@@ -113,7 +110,9 @@ class QuantMatMulQEFT(torch.autograd.Function):
         dtype = scales.dtype
         x16 = x.to(dtype)
         ow16 = oweight.to(dtype).contiguous()
-        y = qeft_cuda.gemm_4bit_qeft(x16, qweight, scales, scaled_zeros, ow16, bias)
+        # (an int32 qweight is the 3-bit extension layout: the same kernels read it directly where their tiers apply)
+        gemm = qeft_cuda.gemm_3bit_qeft if qweight.dtype == torch.int32 else qeft_cuda.gemm_4bit_qeft
+        y = gemm(x16, qweight, scales, scaled_zeros, ow16, bias)
         ctx.save_for_backward(x16, ow16, qweight, scales, scaled_zeros)
         ctx.n_out = n_out
         ctx.in_dtype = x.dtype
@@ -126,7 +125,10 @@ class QuantMatMulQEFT(torch.autograd.Function):
         dy = grad_output.to(scales.dtype).contiguous()
         grad_input = grad_oweight = None
         if ctx.needs_input_grad[0]:
-            grad_input = qeft_cuda.gemm_4bit_dx(dy, qweight, scales, scaled_zeros, ow16).to(ctx.in_dtype)
+            if qweight.dtype == torch.int32:
+                grad_input = qeft_cuda.gemm_3bit_dx(dy, qweight, scales, scaled_zeros, ow16, x16.shape[-1]).to(ctx.in_dtype)
+            else:
+                grad_input = qeft_cuda.gemm_4bit_dx(dy, qweight, scales, scaled_zeros, ow16).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
             grad_oweight = qeft_cuda.grad_oweight(dy, x16, ctx.n_out).to(ctx.ow_dtype)
         return grad_input, grad_oweight, None, None, None, None, None, None
@@ -136,9 +138,11 @@ class QuantMatMul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, qweight, scales, scaled_zeros, n_out, bias, name):
         dtype = scales.dtype
-        y = qeft_cuda.gemm_4bit_qeft(x.to(dtype), qweight, scales, scaled_zeros, None, bias)
+        gemm = qeft_cuda.gemm_3bit_qeft if qweight.dtype == torch.int32 else qeft_cuda.gemm_4bit_qeft
+        y = gemm(x.to(dtype), qweight, scales, scaled_zeros, None, bias)
         ctx.save_for_backward(qweight, scales, scaled_zeros)
         ctx.in_dtype = x.dtype
+        ctx.k = x.shape[-1]
         return y
 
     @staticmethod
@@ -147,7 +151,10 @@ class QuantMatMul(torch.autograd.Function):
         grad_input = None
         if ctx.needs_input_grad[0]:
             dy = grad_output.to(scales.dtype).contiguous()
-            grad_input = qeft_cuda.gemm_4bit_dx(dy, qweight, scales, scaled_zeros, None).to(ctx.in_dtype)
+            if qweight.dtype == torch.int32:
+                grad_input = qeft_cuda.gemm_3bit_dx(dy, qweight, scales, scaled_zeros, None, ctx.k).to(ctx.in_dtype)
+            else:
+                grad_input = qeft_cuda.gemm_4bit_dx(dy, qweight, scales, scaled_zeros, None).to(ctx.in_dtype)
         return grad_input, None, None, None, None, None, None
 
 
@@ -284,34 +291,26 @@ class QuantLinear(nn.Module):
 
     # ------------------------------------------------------------------ 3-bit extension
     def _qweight4(self):
-        """The layer's weights in the 4-bit checkpoint layout (what the GEMM / backward kernels read).  Training keeps
-        one expanded copy per layer (autograd saves it for backward); inference expands into a per-device scratch."""
-        n, k, r = self.outfeatures, self.infeatures, self.outlierfeatures
-        if self.training:
-            c = getattr(self, "_qw4_cache", None)
-            if c is None or c.device != self.qweight.device:
-                c = self._qw4_cache = qeft_cuda.expand_3bit(self.qweight, n, k, r)
-            return c
-        dev = self.qweight.device
-        buf = _W3_SCRATCH.get(dev)
-        if buf is None or buf.numel() < n // 4 * k:
-            buf = _W3_SCRATCH[dev] = torch.empty(n // 4 * k, dtype=torch.int16, device=dev)
-        return qeft_cuda.expand_3bit(self.qweight, n, k, r, out=buf[:n // 4 * k].view(n // 4, k))
+        """The layer's weights expanded to the 4-bit checkpoint layout, a fresh buffer per call (dense dequantisation for the
+        tests / the dense reference, the fused-activation GEMM).  The GEMM forward and backward read the 3-bit stream directly
+        where their loader-wave tiers apply (qeft_cuda.gemm_3bit_qeft / gemm_3bit_dx expand per call otherwise), so no shared
+        scratch and no per-layer expanded copy exist any more."""
+        return qeft_cuda.expand_3bit(self.qweight, self.outfeatures, self.infeatures, self.outlierfeatures)
 
     def _forward_w3(self, x, gather):
         r = self.outlierfeatures
         inputs = torch.index_select(x, -1, self.reorder_ids) if gather else x
         if self.training:
             if r > 0:
-                return self.matmul(inputs, self.oweight, self._qweight4(), self.scales, self.scaled_zeros, r, self.bias,
+                return self.matmul(inputs, self.oweight, self.qweight, self.scales, self.scaled_zeros, r, self.bias,
                                    self.name)
-            return self.matmul(inputs, self._qweight4(), self.scales, self.scaled_zeros, r, self.bias, self.name)
+            return self.matmul(inputs, self.qweight, self.scales, self.scaled_zeros, r, self.bias, self.name)
         seq_len = x.numel() // x.shape[-1]
         if 0 < seq_len <= 16:   # decode / few rows: the 3-bit stream is read directly
             return qeft_cuda.gemv_3bit(inputs, self.qweight, self.scales, self.scaled_zeros,
                                        self.oweight_interleaved if r > 0 else None, self.bias, None, seq_len,
                                        self.outfeatures, self.infeatures, self.group_size, self._szp(x))
-        return qeft_cuda.gemm_4bit_qeft(inputs, self._qweight4(), self.scales, self.scaled_zeros,
+        return qeft_cuda.gemm_3bit_qeft(inputs, self.qweight, self.scales, self.scaled_zeros,
                                         self._outlier_weight_f16() if r > 0 else None, self.bias)
 
     # ------------------------------------------------------------------ forwards (qlinear.py:244-330)

@@ -227,3 +227,56 @@ def test_v3_w3_concat_and_pair(n, k):
     y32 = qeft_cuda.decode_linear(xt, lg, residual=torch.from_numpy(h0).to(DEV))
     torch.cuda.synchronize()
     assert rel_err(y32.cpu().numpy(), h0.astype(np.float64) + g64) < REL_TOL
+
+
+@pytest.mark.parametrize("m,n,k,r,g,tile", [(2048, 4096, 4096, 128, 128, "256x128"), (2048, 11008, 4096, 128, 128, "256x128"),
+                                            (2048, 4096, 11008, 128, 128, "256x128"), (1030, 5904, 1024, 0, 256, "256x128"),
+                                            (600, 4096, 1024, 128, 128, "128x128"), (513, 8208, 640, 128, 64, "128x128")])
+def test_gemm_forward_on_the_3bit_stream(m, n, k, r, g, tile):
+    """BASELINE config 5 (round 3): the prefill / fine-tune forward of a 3-bit layer WITHOUT the 3 -> 4-bit expansion pass -- the
+    loader-wave GEMM tiers read the 12-byte lane records of the 3-bit stream (qeft_gemm_w3).  M = 2048 on the three 7B shapes,
+    ragged tiles, no outlier slice / group 256 / 64, both tile sizes; sampled columns vs the oracle, variant asserted."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=n // 16 + k + 3, bits=3, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=21)
+    y = qeft_cuda.gemm_3bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                 t.get("oweight") if r else None, t["bias"])
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == f"gemm_v3_{tile}_w3", variant
+    w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None, g)
+    rows = np.unique(np.concatenate([np.arange(0, 48), np.arange(n - 48, n), np.random.default_rng(1).integers(0, n, 200)]))
+    yref = x.astype(np.float64) @ w[rows].astype(np.float64).T + bufs["bias"][rows].astype(np.float64)
+    y = y.cpu().numpy()
+    assert y.shape == (m, n)
+    assert rel_err(y[:, rows], yref) < REL_TOL
+    assert elem_err_ok(y[:, rows], yref)
+    # and bit-equal to the expansion route (the same fp16 weights, the same kernel arithmetic)
+    y4 = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), qeft_cuda.expand_3bit(t["qweight"], n, k, r), t["scales"],
+                                  t["scaled_zeros"], t.get("oweight") if r else None, t["bias"])
+    torch.cuda.synchronize()
+    assert np.array_equal(y, y4.cpu().numpy())
+
+
+@pytest.mark.parametrize("m,n,k,r,g", [(2048, 4096, 4096, 128, 128), (2048, 11008, 4096, 128, 128), (2048, 4096, 11008, 128, 128),
+                                       (1100, 448, 6144, 128, 128), (1025, 320, 6144, 0, 256)])
+def test_gemm_dx_on_the_3bit_stream(m, n, k, r, g):
+    """dX = dY . Wdeq of a 3-bit layer from the 3-bit stream (qeft_gemm_w3_dx; the loader waves unpack 12-byte records into the
+    fp16 weight tile): M = 2048 on the 7B shapes, ragged M, a short n loop (7 / 5 tiles: the register ring's remainders)."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=n // 16 + k + 4, bits=3)
+    t = layer_to_torch(bufs, DEV)
+    dy = (np.random.default_rng(5).standard_normal((m, n)) * 0.1).astype(np.float16)
+    dx = qeft_cuda.gemm_3bit_dx(torch.from_numpy(dy).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                t.get("oweight") if r else None, k)
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == "dx256_w3", variant
+    w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None, g)
+    cols = np.unique(np.concatenate([np.arange(0, 64), np.arange(k - 192, k), np.random.default_rng(2).integers(0, k, 200)]))
+    ref = dy.astype(np.float64) @ w[:, cols].astype(np.float64)
+    dx = dx.cpu().numpy()
+    assert dx.shape == (m, k)
+    assert rel_err(dx[:, cols], ref) < REL_TOL
+    assert elem_err_ok(dx[:, cols], ref)

@@ -120,6 +120,22 @@ for (n, k, r) in [(16, 128, 0), (16, 256, 128), (48, 640, 128), (16 * 257, 256, 
     wg = O.dequant_dense(bg["qweight"], bg["scales"], bg["scaled_zeros"], bg.get("oweight") if r else None, 128).astype(np.float64) @ xn
     wu = O.dequant_dense(bu["qweight"], bu["scales"], bu["scaled_zeros"], bu.get("oweight") if r else None, 128).astype(np.float64) @ xn
     assert rel_err(act.cpu().numpy(), wg / (1 + np.exp(-wg)) * wu) < 4e-3, ("hnorm pair", n, k, r)
+# ---- round 3: the 128 x 128 GEMM tier on ragged tiles (M % 128, N % 128 != 0, the minimum K of the rings); the reference's gemv
+# entries on the v3 kernel with the operands as the checkpoint holds them (raw scale rows, interleaved outlier slab, the
+# reorder_ids gather, several batch rows), on the shapes where their clamps bite
+for (n, k, r, g, m) in [(7172, 384, 64, 64, 129), (3588, 512, 128, 128, 530)]:
+    b = O.make_layer(n, k, r, g, seed=n + m)
+    t = layer_to_torch(b, DEV)
+    x = O.make_activation(m, k, r, seed=m)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    assert _lib.last_variant() == "gemm_v3_128x128", _lib.last_variant()
+    torch.cuda.synchronize()
+    ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g)
+    assert rel_err(y.cpu().numpy(), ref.astype(np.float64)) < 1e-3, ("gemm v3 128", n, k, r, g, m)
+for (n, k, r, g, m, gather) in [(16, 256, 128, 128, 1, True), (16, 256, 128, 128, 7, True), (48, 384, 0, 128, 5, False),
+                                (16 * 257, 256, 128, 128, 3, False), (32, 4096, 128, 4096, 2, True), (16, 11008, 128, 128, 7, False)]:
+    gemv(n, k, r, g, m, gather=gather)
+    assert _lib.last_variant().startswith("gemv_v3"), (_lib.last_variant(), n, k, r, g, m)
 lib = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 hh = torch.randn(512, device=DEV); gg = torch.ones(512, device=DEV).half(); ww = (torch.randn(7, 512, device=DEV) * 0.05).half()
