@@ -39,6 +39,64 @@ if len(sys.argv) > 2 and sys.argv[2] == "v3":
             fails.append((case, n, k, r, e))
     print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
     sys.exit(1 if fails else 0)
+if len(sys.argv) > 2 and sys.argv[2] == "ref":
+    # round 3: the REFERENCE's gemv entries (gemv_4bit / gemv_4bit_qeft / the fused form) on the v3 kernel's domain -- operands as
+    # the checkpoint holds them: m = 1..7, group 128 or per-channel, r in {0, 128}, with / without gather, bias, sz_packed shadow
+    for case in range(CASES):
+        n = 16 * int(rng.integers(1, 701))
+        k = 128 * int(rng.integers(2, 91))
+        r = int(rng.choice([0, 128]))
+        g = int(rng.choice([128, 128, k]))
+        m = int(rng.integers(1, 8))
+        gather, bias, shadow = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        b = O.make_layer(n, k, r, g, seed=case, bias=bias)
+        t = layer_to_torch(b, DEV)
+        x = O.make_activation(m, k, r, seed=case)
+        ids = O.sparse_to_dense_ids(np.sort(rng.choice(k, size=max(r, 1), replace=False)), k) if gather else None
+        szp = qeft_cuda.pack_scales(t["scales"], t["scaled_zeros"], n, k, g) if shadow else None
+        y = qeft_cuda.gemv_4bit_fused(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"],
+                                      t.get("oweight_interleaved") if r else None, t.get("bias"),
+                                      torch.from_numpy(ids.astype(np.int32)).to(DEV) if gather else None, None, m, n, k, g, szp)
+        v = _lib.last_variant()
+        torch.cuda.synchronize()
+        ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, b.get("bias"), g, reorder_ids=ids)
+        e = rel_err(y.cpu().numpy(), ref.astype(np.float64))
+        seen[v] = seen.get(v, 0) + 1
+        ok = e < 1e-3 and v.startswith("gemv_v3")
+        print(f"case {case:3d} n={n:5d} k={k:5d} g={g:5d} r={r:3d} m={m} gather={int(gather)} bias={int(bias)} shadow={int(shadow)}  {v:10s} y={e:.1e}" + ("" if ok else "   FAIL"), flush=True)
+        if not ok:
+            fails.append((case, n, k, g, r, m, gather, bias, shadow, v, e))
+    print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
+    sys.exit(1 if fails else 0)
+if len(sys.argv) > 2 and sys.argv[2] == "w3gemm":
+    # round 3: GEMM forward / dX of 3-bit layers: native tiers where they apply, the expansion route otherwise
+    for case in range(CASES):
+        n = 64 * int(rng.integers(4, 100))
+        k = 128 * int(rng.integers(3, 40))
+        r = int(rng.choice([0, 128]))
+        g = int(rng.choice([128, 128, 256 if k % 256 == 0 else 128]))
+        m = int(rng.choice([130, 300, 520, 1024, 1100, 2048]))
+        b = O.make_layer(n, k, r, g, seed=case, bits=3)
+        t = layer_to_torch(b, DEV)
+        x = O.make_activation(m, k, r, seed=case)
+        dy = (np.random.default_rng(case).standard_normal((m, n)) * 0.1).astype(np.float16)
+        ow = t.get("oweight") if r else None
+        y = qeft_cuda.gemm_3bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], ow)
+        v_f = _lib.last_variant()
+        dx = qeft_cuda.gemm_3bit_dx(torch.from_numpy(dy).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], ow, k)
+        v_dx = _lib.last_variant()
+        torch.cuda.synchronize()
+        w = O.dequant_dense(b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, g).astype(np.float64)
+        e_y = rel_err(y.cpu().numpy(), x.astype(np.float64) @ w.T)
+        e_dx = rel_err(dx.cpu().numpy(), dy.astype(np.float64) @ w)
+        for v in (v_f, v_dx):
+            seen[v] = seen.get(v, 0) + 1
+        ok = e_y < 1e-3 and e_dx < 2e-3
+        print(f"case {case:3d} n={n:5d} k={k:5d} g={g:3d} r={r:3d} m={m:4d}  {v_f:22s} {v_dx:12s} y={e_y:.1e} dx={e_dx:.1e}" + ("" if ok else "   FAIL"), flush=True)
+        if not ok:
+            fails.append((case, n, k, g, r, m, v_f, v_dx, e_y, e_dx))
+    print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
+    sys.exit(1 if fails else 0)
 for case in range(CASES):
     k = 64 * int(rng.integers(16, 73) if LARGE else rng.integers(1, 41))      # 64 .. 2560 (large: 1024 .. 4608)
     gs = [g for g in (32, 64, 128, 256) if k % g == 0]
