@@ -191,8 +191,12 @@ int main() {
         }
         CK(hipFree(buf));
     }
+    // "d2": down_proj's bytes as 512 blocks of one row set and half the K (what a 2-way split-K launch would stream, without its
+    // combine step): LAB_SPLITK=1
+    const bool splitk = getenv("LAB_SPLITK") != nullptr;
     const Kind kinds[4] = {{"qkv", 12288, 4096, V3_MODE_PLAIN, true, false}, {"o", 4096, 4096, V3_MODE_PLAIN, false, true},
-                           {"gu", 22016, 4096, V3_MODE_PAIR, true, false}, {"d", 4096, 11008, V3_MODE_PLAIN, false, true}};
+                           {"gu", 22016, 4096, V3_MODE_PAIR, true, false},
+                           splitk ? Kind{"d2", 8192, 5504, V3_MODE_PLAIN, false, true} : Kind{"d", 4096, 11008, V3_MODE_PLAIN, false, true}};
     void* h32 = dalloc(4096 * 4, 1, 0x807fffffu, 0x3f000000u);
     void* gam = dalloc(4096 * 2, 2, 0x03ff03ffu, 0x3c003c00u);
     void* ssq = dalloc(2048 * 4, 3, 0x007fffffu, 0x3f800000u);
@@ -209,7 +213,7 @@ int main() {
         void* y = dalloc(kd.n * 2, 5);
         printf("%s: n=%d k=%d\n", kd.name, kd.n, kd.k);
         const int nsets = kd.n / 16;
-        const int nb = qeft_lab_blocks(nsets);
+        const int nb = (splitk && kd.n == 8192) ? 512 : qeft_lab_blocks(nsets);
         run<8, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
