@@ -36,32 +36,42 @@ int gemv_v3_blocks(int nsets) {
 // What the v3 kernel takes: whole 128-k steps, the checkpoint's r = 128 (or no outlier slice), group 128 or per-channel.
 bool gemv_v3_ok(int K, int G, int n_out) { return K % 128 == 0 && K >= 128 && (n_out == 0 || (n_out == 128 && K > 128)) && (G == 128 || G == K); }
 
-// Instantiations (8 waves per block; the 16-wave form of round 2 lost to it on every launch kind once the step loop had its row
-// sets at compile time, profiles/r03_gemv_lab.txt): ring depth 2 for every RSC, 4 for RSC <= 2, 6 for RSC >= 3.
-template <int D, bool OUTL, int BITS, int RSC>
+// Instantiations.  8 waves per block (the 16-wave form of round 2 lost to it on every launch kind once the step loop had its row
+// sets at compile time, profiles/r03_gemv_lab.txt): ring depth 2 for every RSC, 4 for RSC <= 2, 6 for RSC >= 3.  4 waves per
+// block with ring depth 4 for launches of more than 256 blocks (several blocks per CU: gate|up 10.47 vs 10.76 us).
+template <int NW, int D, bool OUTL, int BITS, int RSC>
 static hipError_t launch_dmr(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
     auto go = [&](auto kern) -> hipError_t {
         if (smem > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(V3_NW * 64), smem, st, V3_KERNEL_ARGS(a));
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
-    if constexpr (D == 2 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches, ring depth 2
-        if (a.m > 1) return go(gemv_v3_kernel<V3_NW, 2, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC>);
+    if constexpr (NW == 8 && D == 2 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches, ring depth 2
+        if (a.m > 1) return go(gemv_v3_kernel<8, 2, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC>);
     }
     if (a.m > 1) return hipErrorInvalidValue;
-    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<V3_NW, D, OUTL, V3_MODE_PAIR, 0, BITS, 1, RSC>) : go(gemv_v3_kernel<V3_NW, D, OUTL, V3_MODE_PLAIN, 0, BITS, 1, RSC>);
+    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR, 0, BITS, 1, RSC>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN, 0, BITS, 1, RSC>);
 }
 
 template <bool OUTL, int BITS>
 static hipError_t launch_d(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
+    if (a.nw == 4) {
+        switch (a.rs_cap) {
+            case 1: return launch_dmr<4, 4, OUTL, BITS, 1>(a, mode, nblk, smem, st);
+            case 2: return launch_dmr<4, 4, OUTL, BITS, 2>(a, mode, nblk, smem, st);
+            case 3: return launch_dmr<4, 4, OUTL, BITS, 3>(a, mode, nblk, smem, st);
+            case 4: return launch_dmr<4, 4, OUTL, BITS, 4>(a, mode, nblk, smem, st);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (a.rs_cap) {           // row sets per block: a compile-time constant of the kernel
-        case 1: return depth >= 4 ? launch_dmr<4, OUTL, BITS, 1>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 1>(a, mode, nblk, smem, st);
-        case 2: return depth >= 4 ? launch_dmr<4, OUTL, BITS, 2>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 2>(a, mode, nblk, smem, st);
-        case 3: return depth >= 4 ? launch_dmr<6, OUTL, BITS, 3>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 3>(a, mode, nblk, smem, st);
-        case 4: return depth >= 4 ? launch_dmr<6, OUTL, BITS, 4>(a, mode, nblk, smem, st) : launch_dmr<2, OUTL, BITS, 4>(a, mode, nblk, smem, st);
+        case 1: return depth >= 4 ? launch_dmr<8, 4, OUTL, BITS, 1>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 1>(a, mode, nblk, smem, st);
+        case 2: return depth >= 4 ? launch_dmr<8, 4, OUTL, BITS, 2>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 2>(a, mode, nblk, smem, st);
+        case 3: return depth >= 4 ? launch_dmr<8, 6, OUTL, BITS, 3>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 3>(a, mode, nblk, smem, st);
+        case 4: return depth >= 4 ? launch_dmr<8, 6, OUTL, BITS, 4>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 4>(a, mode, nblk, smem, st);
     }
     return hipErrorInvalidValue;
 }
@@ -85,7 +95,10 @@ static bool gemv_v3_plan(V3Args& a, int& nw, size_t& smem) {
     a.sets_q = a.g.nsets / nblk;
     a.sets_r = a.g.nsets % nblk;
     if (a.m < 1) a.m = 1;
-    nw = V3_NW;
+    static const int f_nw = env_int("QEFT_GEMV_NW");      // lab override: 4 or 8
+    // several blocks per CU (more than 256 blocks): 4-wave blocks, one wave per SIMD each
+    nw = f_nw == 4 || f_nw == 8 ? f_nw : (nblk > 256 && a.m <= 1 ? 4 : V3_NW);
+    if (a.m > 1) nw = V3_NW;
     a.nw = nw;
     smem = v3_lds(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.m, nw, a.xn_gamma != nullptr && a.szp != nullptr, a.szp == nullptr, a.ids != nullptr).total;
     return smem <= 160 * 1024 && nblk < 65536;       // (nblk, sets_r share dwords with rs_cap, sets_q)
@@ -113,7 +126,7 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     // at least 8 loads to make, 4 loads in flight per wave (6 with three or four row sets per block: two whole steps) --
     // q|k|v 7.06 (6) / 7.44 (4) / 7.69 us (2), down_proj 7.18 (4) / 7.59 (2); short launches (o_proj: 4 loads per wave) and
     // two blocks per CU (gate|up) keep 2: 4.58 vs 4.78, 10.97 vs 11.07 / 11.50.
-    const int loads_per_wave = ceil_div(a.g.nfull, V3_NW) * a.rs_cap;
+    const int loads_per_wave = ceil_div(a.g.nfull, nw) * a.rs_cap;
     const int depth = f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 && a.m <= 1 ? 4 : 2);
     const bool w3 = a.bits == 3;
     g_last_variant = a.m > 1 ? "gemv_v3_mb" : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
@@ -153,7 +166,7 @@ long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq
                     for (int j = 0; j < 4; ++j) bad += v3_ow_off(set0 + rs, j, lane) + 16 > ow_bytes;
                 if (kc == 0) bad += (set0 + rs) * 16 + nl >= n_rows_have;
             }
-            for (int NW = 8; NW <= 16; NW += 8)        // both instantiations of the kernel
+            for (int NW = 4; NW <= 16; NW *= 2)        // every wave count the kernel is (or was) instantiated with
                 for (int wave = 0; wave < NW; ++wave) {
                     const int nsw = (G.nfull - wave + NW - 1) / NW;
                     const uint32_t stepb = bits == 3 ? 768u : 256u, last = bits == 3 ? v3w3_last_step_off(G) : v3_last_step_off(G);
@@ -181,7 +194,7 @@ long long gemv_v3_count_out_of_range_ckpt(const V3Geom& G, int n_rows_have, int 
     const int nblk = gemv_v3_blocks(G.nsets), rs_cap = ceil_div(G.nsets, nblk);
     const int XB = v3_x_bytes(G.K), SRB = v3_szraw_bytes(G.ngroups), XS = v3_x_stride(G.K, m);
     // (the strided scale rows assume the operand really has G.nsets * 16 columns: a shrunk operand is the negative control)
-    for (int nw = 8; nw <= 16; nw += 8) {
+    for (int nw = 4; nw <= 16; nw *= 2) {
         const V3Lds L = v3_lds(G.K, G.ngroups, G.n_out, rs_cap, m, nw, false, true, gather);
         if (L.total > 160 * 1024) continue;     // not launched (gemv_v3_plan)
         for (int b = 0; b < nblk; ++b) {

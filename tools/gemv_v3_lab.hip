@@ -102,10 +102,10 @@ static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h3
     const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
     auto f = [a, &B, &kd, nblk, smem](int l) {
         V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
-        if (kd.mode == V3_MODE_PAIR) { if constexpr (NW == 8) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); }
+        if (kd.mode == V3_MODE_PAIR) { if constexpr (NW <= 8) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); }
         else launch<NW, D, V3_MODE_PLAIN, ABL>(b, nblk, smem);
     };
-    if (kd.mode == V3_MODE_PAIR && NW != 8) return;
+    if (kd.mode == V3_MODE_PAIR && NW > 8) return;
     const double bytes = (double)kd.n * (kd.k - 128) / 2 + 2.0 * (kd.k / 128) * kd.n * 2 + (double)kd.n * 128 * 2 + 2 * kd.k + 2 * kd.n;
     char label[96];
     snprintf(label, sizeof label, "%-4s NW=%2d D=%d blocks=%4d ABL=%2d", kd.name, NW, D, nblk, ABL);
@@ -219,6 +219,11 @@ int main() {
         run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 4, 16>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        if (getenv("LAB_NW4")) {
+            run<4, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+            run<4, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+            run<4, 8, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        }
         measure_cases(7);
         if (full) {
             timeline<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
