@@ -8,6 +8,6 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o run --output-format csv -- python3 $OLDPWD/bench.py --no-traffic > $OUT/bench.json 2> $OUT/bench.err
 echo "rc=$?"
 cd $OLDPWD
-python3 tools/summarize_rocprof.py $OUT/kt gpurun_out/r2_bench_kernel_stats.txt
-head -40 gpurun_out/r2_bench_kernel_stats.txt
+python3 tools/summarize_rocprof.py $OUT/kt gpurun_out/r03_bench_kernel_stats.txt
+head -40 gpurun_out/r03_bench_kernel_stats.txt
 tail -c 600 $OUT/bench.json
