@@ -384,7 +384,13 @@ def mid_m_records(dev, ms=(64, 512, 1024), layers=4, reps=25):
                 for qw, sc, sz, ow in ws:
                     qeft_cuda.gemm_4bit_qeft(x, qw, sc, sz, ow)
                 var["v"] = _lib.last_variant()
-            t = _event_time_us(fwd, reps, dev) / layers
+            fwd()                               # (allocates the split-K workspace outside the capture)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()      # replayed: two short launches per call are host-bound when issued eagerly
+            with torch.cuda.graph(graph):
+                fwd()
+            t = _event_time_us(graph.replay, reps, dev) / layers
+            del graph
             fl = 2.0 * m * n * k
             rec[f"M{m}"] = {"us": round(t, 1), "TFLOPs": round(fl / t / 1e6, 1), "frac_of_peak": round(fl / t / 1e6 / MFMA_PEAK_TFLOPS, 4),
                             "variant": var["v"]}

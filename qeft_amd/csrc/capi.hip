@@ -58,6 +58,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
 int gemm_w3_native_tile(int M, int N, int K, int G, int n_out);
 bool gemm_w3_dx_native(int M, int N, int K, int G, int n_out);
 int gemm_w4_split(int M, int N, int K, int n_out);
+int gemm_v3_split(int M, int N, int K, int n_out);
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace = nullptr,
                              size_t workspace_bytes = 0, int bits = 4);
@@ -321,7 +322,9 @@ int qeft_gemm_w3_dx(const void* dy, const void* qweight3, const void* scales, co
 
 long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {
     if (m < 1 || n < 1 || k < 1 || n_out < 0 || n_out >= k || small_m_route(m, n, true)) return 0;
-    const int s = qeft::gemm_w4_split(m, n, k, n_out);
+    int s = qeft::gemm_w4_split(m, n, k, n_out);
+    const int s3 = qeft::gemm_v3_split(m, n, k, n_out);       // the loader-wave tier's split (whichever tier the launch takes, it fits)
+    if (s3 > s) s = s3;
     return s > 1 ? (long long)s * m * n * 4 : 0;
 }
 

@@ -495,7 +495,10 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                                                            const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                            const f16* __restrict__ ow, const f16* __restrict__ bias,
                                                            f16* __restrict__ y, int M, int N, int K, int G, int n_out, int NB,
-                                                           const f16* __restrict__ gate) {
+                                                           const f16* __restrict__ gate, float* __restrict__ part, int S) {
+    // Split-K (part != NULL, S > 1; round 3): the grid holds S blocks per output tile, block z of a tile contracts the k-tiles
+    // [z KT, (z + 1) KT) (KT = K / 64 / S; the fp16 outlier k-tiles fall to the last block) and writes an fp32 partial tile to
+    // part[z][M][N]; gemm_splitk_reduce_kernel sums the S partials in order, adds the bias and rounds once (deterministic).
     // 8 waves, two per SIMD with fixed roles: waves 0..3 compute (wave w: columns 32 w .. 32 w + 31 of the tile, all 256 rows),
     // waves 4..7 load (wave 4 + l: activation pieces 8 l .. 8 l + 7, the packed weights of compute wave l, scales / zeros).
     // An LDS-DMA instruction holds its wave for 100-200 cycles at issue; in the compute waves' own stream (first version)
@@ -513,10 +516,11 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through consecutive tiles of one row block
     const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
     const int c = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
-    const int bm0 = (c / NB) * BMR, bn0 = (c % NB) * G3_BN;
-    const int ktiles = K / BK;
+    const int tiles = nblk / S, zsp = c / tiles, ct = c - zsp * tiles;
+    const int bm0 = (ct / NB) * BMR, bn0 = (ct % NB) * G3_BN;
+    const int ktiles = K / BK / S, kt0 = zsp * ktiles;      // this block's k-tiles: global kt0 .. kt0 + ktiles - 1, local index t
     const int kq = K - (OUTL ? n_out : 0);
-    const int qtiles = kq / BK;            // INT4 k-tiles [0, qtiles); fp16 outlier k-tiles [qtiles, ktiles)
+    const int qtiles = min(max(kq / BK - kt0, 0), ktiles);   // local INT4 k-tiles [0, qtiles); fp16 outlier k-tiles [qtiles, ktiles)
     constexpr int LEAD = G3_ST - 1, LEAD_B = G3_BST - 1;
 
     if (wave >= 4) {
@@ -542,14 +546,15 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const uint8_t* const sz_base = (const uint8_t*)(l == 0 ? scales : zeros);
         auto stage_a = [&](int t) {            // 8 DMA instructions
             if (ABL == 1 || ABL >= 3) return;
-            g3_dma_a((const uint8_t*)x + (size_t)t * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * A_B + (uint32_t)l * (AP * 1024u));
+            g3_dma_a((const uint8_t*)x + (size_t)(kt0 + t) * (BK * 2), a_off, lds0 + (uint32_t)(t & (G3_ST - 1)) * A_B + (uint32_t)l * (AP * 1024u));
         };
         auto stage_b = [&](int t, int slot) {  // 2 (l < 2) or 1 DMA instructions
             if (ABL == 1 || ABL >= 3) return;
-            g3_dma16(qw + (BITS == 3 ? (size_t)(t >> 1) * 768 + (size_t)(t & 1) * 384 : (size_t)t * 128), b_off,
+            const int tg = kt0 + t;
+            g3_dma16(qw + (BITS == 3 ? (size_t)(tg >> 1) * 768 + (size_t)(tg & 1) * 384 : (size_t)tg * 128), b_off,
                      lds0 + BOFF + (uint32_t)slot * G3_B + (uint32_t)l * 1024u);
             if (l < 2)
-                g3_dma4(sz_base + (size_t)((t * BK) >> gshift) * N * 2, s_off, lds0 + SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
+                g3_dma4(sz_base + (size_t)((tg * BK) >> gshift) * N * 2, s_off, lds0 + SOFF + (uint32_t)slot * G3_S + (uint32_t)l * 256u);
         };
         // In-order completion: at the top of iteration t the activations of k-tile t + 1 (the LAST thing iteration t - 2
         // issued) must have landed; younger than them is exactly what iteration t - 1 issued: [weights / scales of k-tile
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
         const h2 sc = splat(sn_), zc = splat(zn_);
         h2 qx[4];
         if (TAIL && OUTL && has_next) {
-            const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + ((t + 1) * BK + h * 32 - kq));
+            const u32x4* p = (const u32x4*)(ow + (size_t)ncol * n_out + ((kt0 + t + 1) * BK + h * 32 - kq));
 #pragma unroll
             for (int j = 0; j < 4; ++j) bn[j] = p[j];
         }
@@ -776,6 +781,26 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
     // row segments, 16 bytes per lane: the direct form (2-byte stores, 64 bytes per row per instruction) cost ~10 us per block.
     __builtin_amdgcn_s_barrier();              // every compute wave is done with the ring (the loader waves have exited)
     asm volatile("" ::: "memory");
+    if (part != nullptr) {                     // split-K: the fp32 partial tile, through LDS, as whole 512-byte row segments
+        constexpr int PP = G3_BN * 4 + 16;     // pitch of the fp32 tile in LDS (128 rows: 66 KB, 256 rows: 132 KB of the free rings)
+        uint8_t* const colp = lds + nloc * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                *(float*)(colp + (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * PP) = acc[mt][e];
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int ch = lane & 31, n0 = bn0 + ch * 4;
+        float* const pz = part + (size_t)zsp * M * N;
+#pragma unroll 4
+        for (int i = 0; i < 4 * MT; ++i) {     // wave w: rows w * 8 MT + 2 i + lane / 32
+            const int row = wave * (8 * MT) + i * 2 + (lane >> 5), m = bm0 + row;
+            if (m >= M || n0 >= N) continue;
+            *(f32x4*)(pz + (size_t)m * N + n0) = *(const f32x4*)(lds + row * PP + ch * 16);
+        }
+        return;
+    }
     // SILU: the gate segments of the 16 row groups this lane stores below, fetched four groups at a time, the first two
     // batches before the tile goes to LDS (clamped addresses, unconditional loads)
     u32x4 ga[4], gb[4];
@@ -892,6 +917,16 @@ bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out) {
            (size_t)M * K * 2 < (1ull << 32) && (size_t)(n2 / 4) * K * 2 < (1ull << 32);
 }
 
+// Split factor of the 128-row loader-wave tier (round 3): S blocks per tile when the tiles alone fill less than 3/4 of the CUs --
+// the largest S <= 256 / tiles that divides the k-tile count, leaves every block >= 8 k-tiles and the last block >= 2 INT4 ones.
+int gemm_v3_split(int M, int N, int K, int n_out) {
+    const int tiles = ((M + 127) / 128) * ((N + G3_BN - 1) / G3_BN), kt = K / BK;
+    if (tiles >= 192 || tiles < 1 || K % BK != 0) return 1;
+    for (int s = 256 / tiles > 16 ? 16 : 256 / tiles; s >= 2; --s)
+        if (kt % s == 0 && kt / s >= 8 && kt / s - n_out / BK >= 2) return s;
+    return 1;
+}
+
 // The tiers that read the 3-bit extension layout directly (0: none -- expand first; 8 / 4: the 256- / 128-row loader-wave tile)
 int gemm_w3_native_tile(int M, int N, int K, int G, int n_out) {
     const int nb = (N + G3_BN - 1) / G3_BN;
@@ -919,7 +954,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(mbt * nb), dim3(512), smem, st, (const f16*)x, (const uint8_t*)qw, (const f16*)scales,
                                (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias, (f16*)y, M, N, K, G,
-                               outl ? n_out : 0, nb, (const f16*)nullptr);
+                               outl ? n_out : 0, nb, (const f16*)nullptr, (float*)nullptr, 1);
             return hipGetLastError();
         };
         g_last_variant = tile == 8 ? "gemm_v3_256x128_w3" : "gemm_v3_128x128_w3";
@@ -943,7 +978,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(kern, dim3(mb * nb), dim3(512), G3_SMEM, st, (const f16*)x, (const uint8_t*)qw,
                                    (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
-                                   (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)silu_gate);
+                                   (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)silu_gate, (float*)nullptr, 1);
                 return hipGetLastError();
             };
             if (silu_gate == kSiluPair64) {
@@ -975,6 +1010,27 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         {
             static const int force_m = getenv("QEFT_GEMM_V3M") ? atoi(getenv("QEFT_GEMM_V3M")) : -1;
             const int mb4 = (M + 127) / 128;
+            // fewer than 192 tiles and a workspace: S blocks per tile, fp32 partials, the reduce launch (QEFT_GEMM_V3S=0 disables)
+            static const int force_s = getenv("QEFT_GEMM_V3S") ? atoi(getenv("QEFT_GEMM_V3S")) : -1;
+            const int S3 = (force_s == 0 || force_m == 0 || !workspace || silu_gate || !ok3 || M <= 16) ? 1 : gemm_v3_split(M, N, K, outl ? n_out : 0);
+            if (S3 > 1 && workspace_bytes >= (size_t)S3 * M * N * 4) {
+                constexpr int SMEM4 = G3_ST * 128 * BK * 2 + G3_BST * G3_B + G3_BST * G3_S;
+                auto go4 = [&](auto kern) -> hipError_t {
+                    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM4);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(kern, dim3(mb4 * nb * S3), dim3(512), SMEM4, st, (const f16*)x, (const uint8_t*)qw,
+                                       (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)nullptr,
+                                       (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)nullptr, (float*)workspace, S3);
+                    return hipGetLastError();
+                };
+                g_last_variant = "gemm_v3_128x128+splitk";
+                hipError_t e = outl ? go4(gemm_w4_kernel_v3<true, 0, 0, 4>) : go4(gemm_w4_kernel_v3<false, 0, 0, 4>);
+                if (e != hipSuccess) return e;
+                const size_t quads = (size_t)M * N / 4;
+                hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((int)((quads + 255) / 256)), dim3(256), 0, st,
+                                   (const float*)workspace, (const f16*)bias, (f16*)y, M, N, S3);
+                return hipGetLastError();
+            }
             if (ok3 && !silu_gate && (force_m == 1 || (force_m != 0 && mb4 * nb >= 112 && M > 128))) {
                 constexpr int SMEM4 = G3_ST * 128 * BK * 2 + G3_BST * G3_B + G3_BST * G3_S;         // 93184 bytes
                 auto go4 = [&](auto kern) -> hipError_t {
@@ -982,7 +1038,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
                     if (e != hipSuccess) return e;
                     hipLaunchKernelGGL(kern, dim3(mb4 * nb), dim3(512), SMEM4, st, (const f16*)x, (const uint8_t*)qw,
                                        (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (const f16*)bias,
-                                       (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)nullptr);
+                                       (f16*)y, M, N, K, G, outl ? n_out : 0, nb, (const f16*)nullptr, (float*)nullptr, 1);
                     return hipGetLastError();
                 };
                 g_last_variant = "gemm_v3_128x128";

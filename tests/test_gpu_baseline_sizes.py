@@ -109,7 +109,7 @@ def test_variant_names_follow_the_routing():
         seen[m] = _lib.last_variant()
     torch.cuda.synchronize()
     assert seen[8] == "gemv_smallm", seen
-    assert seen[200].startswith("gemm_v2_128x128"), seen
+    assert seen[200] == "gemm_v3_128x128+splitk", seen           # 8 tiles: two blocks per tile through the split-K workspace
     dy = torch.zeros(64, n, dtype=torch.float16, device=DEV)
     qeft_cuda.gemm_4bit_dx(dy, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
     assert _lib.last_variant().startswith("dx64")
@@ -201,3 +201,28 @@ def test_gemm_mid_m_tier_128_row_tiles(m, n, k, r, g):
     assert y.shape == (m, n)
     assert rel_err(y, yref) < REL_TOL
     assert elem_err_ok(y, yref)
+
+
+@pytest.mark.parametrize("m,n,k,r,g", [(64, 4096, 4096, 128, 128), (200, 520, 1024, 128, 128), (100, 11008, 4096, 128, 128),
+                                       (512, 4096, 11008, 128, 128), (17, 1000, 2048, 0, 256), (300, 4096, 1536, 64, 64)])
+def test_gemm_split_k_on_the_loader_wave_tile(m, n, k, r, g):
+    """Fewer than 192 tiles of 128 x 128: S blocks per tile contract K / S each (the fp16 outlier k-tiles fall to the last one),
+    fp32 partial tiles through the workspace, the ordered reduce launch (round 3; deterministic).  M = 17 .. 512 incl. the
+    64-token prompt of benchmark.py, ragged M and N, S = 2 .. 8, no outlier slice / 64 columns; full output vs the oracle."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=m + n + k, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, r, seed=31)
+    xt = torch.from_numpy(x).to(DEV)
+    y = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None, t["bias"])
+    variant = _lib.last_variant()
+    y2 = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None, t["bias"])
+    torch.cuda.synchronize()
+    assert variant == "gemm_v3_128x128+splitk", variant
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None,
+                          bufs["bias"], g).astype(np.float64)
+    y = y.cpu().numpy()
+    assert y.shape == (m, n)
+    assert rel_err(y, yref) < REL_TOL
+    assert elem_err_ok(y, yref)
+    assert np.array_equal(y, y2.cpu().numpy())          # ordered sum of the partials: run to run bit-identical
