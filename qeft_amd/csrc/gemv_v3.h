@@ -1,4 +1,6 @@
-// Decode GEMV, third formulation ("v3"): the batch-1 production path of the decode engine.
+// Decode GEMV, third formulation ("v3"): the production GEMV -- the decode engine's launches (one packed operand per launch,
+// derived buffers of qeft_amd/fuse.py) and, since round 3, the reference's own entry points gemv_4bit / gemv_4bit_qeft /
+// QuantLinear.forward for m = 1..7 on the operands as the checkpoint holds them (see the list at the end of this comment).
 //
 // Same MFMA mapping as gemv_w4_mfma.h (one wave-wide 16 B/lane load = 16 rows x 128 k = four B fragments of
 // v_mfma_f32_16x16x32_f16, x as the A operand from LDS), but the per-block prologue is gone.  Round 1 measured the launch as
@@ -25,7 +27,19 @@
 //                 both halves and stores silu(gate) * up directly.
 //   * one operand per launch: q|k|v are concatenated at load time, so the kernel has no per-part logic.
 //   * the outlier step takes its B fragments from the PLAIN oweight [N, r] rows (64 contiguous bytes per lane, gathered by
-//     the DMA into an XOR-swizzled LDS image), not from oweight_interleaved.
+//     the DMA into an XOR-swizzled LDS image) -- or, for the reference's entries, from oweight_interleaved (below).
+//
+// Round 3:
+//   * the block's row-set count is a template parameter (RSC): ring slot, accumulator and scale row of every (step, row set)
+//     are fixed in the code (the run-time bookkeeping of round 2's loop was a third of its instructions); 8-wave blocks
+//     (4-wave blocks for launches of more than 256 blocks), ring depth 2 / 4 / 6 chosen by the launcher (gemv_v3.hip);
+//   * checkpoint-layout operands, selected by run-time flags (V3_F_*), all handled LDS -> LDS in the phase between the staging
+//     barrier and the first step, while the first weight loads are in flight:
+//       V3_F_SZN     scales / scaled_zeros fp16 [K/g][N] staged raw (32 B per group and row set) and packed into the words above;
+//       V3_F_OWIL    the outlier slab from oweight_interleaved [N/2][2r] (qlinear.py:70-79), de-interleaved by v_perm_b32 in the
+//                    outlier step;
+//       V3_F_GATHER  x[:, reorder_ids] (qlinear.py:275): ids and raw rows by DMA, the gather in LDS;
+//     and MB = 2 instantiations for m = 2..7 batch rows (the A rows of the same MFMAs; x rows 16 bytes askew in LDS).
 //
 // Address arithmetic lives in __host__ __device__ functions shared with a host-side enumerator
 // (qeft_gemv_v3_check_extents, capi.hip) that walks every block / wave / lane / piece / step of a configuration and
@@ -36,8 +50,8 @@
 
 namespace qeft {
 
-constexpr int V3_NW = 8;        // waves per block (the kernel is also instantiated with 16); wave w owns the 128-k steps w, w + NW, ...
-constexpr int V3_NW_MAX = 16;
+constexpr int V3_NW = 8;        // waves per block (4 for launches of more than 256 blocks); wave w owns the 128-k steps w, w + NW, ...
+constexpr int V3_NW_MAX = 16;   // LDS sizing of the per-wave partial sums (the lab still instantiates 16-wave blocks)
 constexpr int V3_MAX_RS = 4;    // 16-row sets per block (LDS is carved for rs_cap <= 4)
 constexpr int V3_MAX_SSQ = 512; // partial sums of squares a consumer accepts
 constexpr int V3_MODE_PLAIN = 0;

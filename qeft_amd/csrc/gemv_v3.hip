@@ -19,8 +19,8 @@ int gemv_v3_blocks(int nsets) {
     int nblk;
     if (forced > 0) nblk = nsets < forced ? nsets : forced;
     else if (nsets <= 256) nblk = nsets;
-    else if (nsets < 512) nblk = ceil_div(nsets, 2);     // the fullest CU carries two sets either way; one 16-wave block of two
-                                                         // beats two 8-wave blocks (Llama-2-13B down_proj, 320 sets: 12.0 -> 10.8 us)
+    else if (nsets < 512) nblk = ceil_div(nsets, 2);     // the fullest CU carries two sets either way: one block of two (staging paid
+                                                         // once) rather than two blocks (round 2, Llama-2-13B down_proj, 320 sets: 12.0 -> 10.8 us)
     else {
         int k = (nsets + 384) / 768;
         if (k < 1) k = 1;
