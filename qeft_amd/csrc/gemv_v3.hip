@@ -49,8 +49,8 @@ static hipError_t launch_dmr(const V3Args& a, int mode, int nblk, size_t smem, h
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
-    if constexpr (NW == 8 && D == 2 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches, ring depth 2
-        if (a.m > 1) return go(gemv_v3_kernel<8, 2, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC>);
+    if constexpr (NW == 8 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches
+        if (a.m > 1) return go(gemv_v3_kernel<8, D, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC>);
     }
     if (a.m > 1) return hipErrorInvalidValue;
     return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR, 0, BITS, 1, RSC>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN, 0, BITS, 1, RSC>);
@@ -124,10 +124,10 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     static const int f_d = env_int("QEFT_GEMV_DEPTH");     // lab override: 2, or 4 (= the deep form of the block's RSC: 4 or 6 loads)
     // Ring depth (tools/gemv_v3_lab.hip, interleaved timing, profiles/r03_gemv_lab.txt): where a CU holds ONE block and a wave has
     // at least 8 loads to make, 4 loads in flight per wave (6 with three or four row sets per block: two whole steps) --
-    // q|k|v 7.06 (6) / 7.44 (4) / 7.69 us (2), down_proj 7.18 (4) / 7.59 (2); short launches (o_proj: 4 loads per wave) and
+    // q|k|v 7.06 (6) / 7.44 (4) / 7.69 us (2), down_proj 7.18 (4) / 7.59 (2) (the batch-row launches likewise: 8.65 vs 8.81); short launches (o_proj: 4 loads per wave) and
     // two blocks per CU (gate|up) keep 2: 4.58 vs 4.78, 10.97 vs 11.07 / 11.50.
     const int loads_per_wave = ceil_div(a.g.nfull, nw) * a.rs_cap;
-    const int depth = f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 && a.m <= 1 ? 4 : 2);
+    const int depth = f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 ? 4 : 2);
     const bool w3 = a.bits == 3;
     g_last_variant = a.m > 1 ? "gemv_v3_mb" : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
     return w3 ? launch_b<3>(a, mode, a.nblk, smem, depth, st) : launch_b<4>(a, mode, a.nblk, smem, depth, st);
