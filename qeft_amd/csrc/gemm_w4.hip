@@ -917,6 +917,17 @@ bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out) {
            (size_t)M * K * 2 < (1ull << 32) && (size_t)(n2 / 4) * K * 2 < (1ull << 32);
 }
 
+// 256-row or 128-row loader-wave tile?  One block per CU either way; a launch takes ceil(tiles / 256) rounds of blocks and a
+// 256-row block takes ~1.7x a 128-row block (it is the more efficient one per flop).  M >= 1024 with >= 224 tiles of 256 rows is
+// round 2's rule and stays; below that the 256-row tile also wins where the 128-row tiles would need a second, mostly empty round
+// (11008 x 4096 at M = 512: 344 tiles of 128 rows = 2 rounds, 172 tiles of 256 rows = one).
+static bool gemm_v3_prefers_256(int M, int N) {
+    const int nb = (N + G3_BN - 1) / G3_BN, t8 = ((M + G3_BM - 1) / G3_BM) * nb, t4 = ((M + 127) / 128) * nb;
+    if (t8 >= 224 && M >= 1024) return true;
+    if (M <= 256 || t8 < 129) return false;
+    return 1.7 * ((t8 + 255) / 256) < 1.0 * ((t4 + 255) / 256);
+}
+
 // Split factor of the 128-row loader-wave tier (round 3): S blocks per tile when the tiles alone fill less than 3/4 of the CUs --
 // the largest S <= 256 / tiles that divides the k-tile count, leaves every block >= 8 k-tiles and the last block >= 2 INT4 ones.
 int gemm_v3_split(int M, int N, int K, int n_out) {
@@ -934,7 +945,7 @@ int gemm_w3_native_tile(int M, int N, int K, int G, int n_out) {
                     (G & (G - 1)) == 0 && G >= 64 && (size_t)M * K * 2 < (1ull << 32) &&
                     (size_t)(N / 16) * ((K - n_out) / 128) * 768 < (1ull << 32);
     if (!ok) return 0;
-    if (((M + G3_BM - 1) / G3_BM) * nb >= 224 && M >= 1024) return 8;
+    if (gemm_v3_prefers_256(M, N)) return 8;
     if (((M + 127) / 128) * nb >= 112 && M > 128) return 4;
     return 0;
 }
@@ -971,7 +982,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
         const bool ok3 = K / BK >= G3_BST && K % BK == 0 && (!outl || n_out % 64 == 0) && (K - (outl ? n_out : 0)) / BK >= 2 &&
                          (G & (G - 1)) == 0 && G >= 64 && N % 4 == 0 && N >= 2 && (size_t)M * K * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32);
         if (silu_gate == kSiluPair64 && !(ok3 && N % 128 == 0)) return hipErrorNotSupported;     // capi checks gemm_w4_pair64_ok first
-        if (ok3 && (silu_gate == kSiluPair64 || force_v3 == 1 || (force_v3 != 0 && mb * nb >= 224 && M >= 1024)) &&
+        if (ok3 && (silu_gate == kSiluPair64 || force_v3 == 1 || (force_v3 != 0 && gemm_v3_prefers_256(M, N))) &&
             (!silu_gate || N % 8 == 0)) {
             auto go3 = [&](auto kern) -> hipError_t {
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_SMEM);
