@@ -287,20 +287,25 @@ __host__ __device__ constexpr int v3_unroll_steps(int D, int RSC) {
 //      factors in front of four accumulators, three branches per consume) was a third of its ~95 instructions per 1 KB of
 //      weights.  A launch's blocks hold RSC sets, except at most RSC - 1 blocks that hold one fewer (gemv_v3_blocks): those
 //      stream their last set twice and drop the copy's results.
-template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1>
+// FL: the run-time flags (V3_F_*: per-channel scales, consumer-side norm, checkpoint-layout operands, gather) are honoured; false
+//     for the plain launches of the decode engine, which then carry no trace of those paths.
+template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1, bool FL = true>
 __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
     static_assert(BITS == 4 || BITS == 3, "4-bit checkpoint layout or the 3-bit extension layout (oracle: pack_w3)");
     static_assert(MB == 1 || (MODE == V3_MODE_PLAIN && BITS == 4), "several batch rows: plain 4-bit launches only");
     static_assert(RSC >= 1 && RSC <= V3_MAX_RS && D >= 2, "row sets per block 1..4, at least two loads in flight per wave");
+    static_assert(FL || MB == 1, "the batch-row launches always come with flags");
     typedef typename V3Val<MB>::type val_t;
     // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
     // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
     // dependent scalar-memory round trip in the middle of the stream
-    const bool per_channel_f = (nblk_rscap_flags & V3_F_PERCH) != 0, XN = MB == 1 && (nblk_rscap_flags & V3_F_XN) != 0;
-    const bool SZN = (nblk_rscap_flags & V3_F_SZN) != 0, OWIL = OUTL && (nblk_rscap_flags & V3_F_OWIL) != 0;
-    const bool GATHER = (nblk_rscap_flags & V3_F_GATHER) != 0;
+    // (FL == false: the launcher guarantees that no flag is set -- the decoding and the never-taken transform branches cost a
+    //  plain launch ~0.12 us of prologue, profiles/r03_gemv_lab.txt)
+    const bool per_channel_f = FL && (nblk_rscap_flags & V3_F_PERCH) != 0, XN = FL && MB == 1 && (nblk_rscap_flags & V3_F_XN) != 0;
+    const bool SZN = FL && (nblk_rscap_flags & V3_F_SZN) != 0, OWIL = FL && OUTL && (nblk_rscap_flags & V3_F_OWIL) != 0;
+    const bool GATHER = FL && (nblk_rscap_flags & V3_F_GATHER) != 0;
     const int m = MB == 1 ? 1 : (int)((nblk_rscap_flags >> V3_F_M_SHIFT) & 7u) + 1;
     const int nblk = (int)(nblk_rscap_flags & 0xffffu);
     const int sets_q = (int)(setsq_setsr & 0xffffu), sets_r = (int)(setsq_setsr >> 16);

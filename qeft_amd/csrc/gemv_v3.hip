@@ -2,10 +2,12 @@
 #include <cstdlib>
 
 #include "gemv_v3.h"
+#include "gemv_v3_dispatch.h"
 
 namespace qeft {
 
 static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+hipError_t gemv_v3_dispatch_plain(const V3Args& a, int mode, size_t smem, int depth, hipStream_t st);     // gemv_v3_plain.hip
 
 // Blocks for `nsets` 16-row sets: one set per block while that leaves the 256 CUs two blocks each at most; wide launches
 // run about 256 k long-lived blocks of ~3 sets (the ring then never drains between sets and the staging is paid once per
@@ -35,51 +37,6 @@ int gemv_v3_blocks(int nsets) {
 
 // What the v3 kernel takes: whole 128-k steps, the checkpoint's r = 128 (or no outlier slice), group 128 or per-channel.
 bool gemv_v3_ok(int K, int G, int n_out) { return K % 128 == 0 && K >= 128 && (n_out == 0 || (n_out == 128 && K > 128)) && (G == 128 || G == K); }
-
-// Instantiations.  8 waves per block (the 16-wave form of round 2 lost to it on every launch kind once the step loop had its row
-// sets at compile time, profiles/r03_gemv_lab.txt): ring depth 2 for every RSC, 4 for RSC <= 2, 6 for RSC >= 3.  4 waves per
-// block with ring depth 4 for launches of more than 256 blocks (several blocks per CU: gate|up 10.47 vs 10.76 us).
-template <int NW, int D, bool OUTL, int BITS, int RSC>
-static hipError_t launch_dmr(const V3Args& a, int mode, int nblk, size_t smem, hipStream_t st) {
-    auto go = [&](auto kern) -> hipError_t {
-        if (smem > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
-        return hipGetLastError();
-    };
-    if constexpr (NW == 8 && BITS == 4) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches
-        if (a.m > 1) return go(gemv_v3_kernel<8, D, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC>);
-    }
-    if (a.m > 1) return hipErrorInvalidValue;
-    return mode == V3_MODE_PAIR ? go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PAIR, 0, BITS, 1, RSC>) : go(gemv_v3_kernel<NW, D, OUTL, V3_MODE_PLAIN, 0, BITS, 1, RSC>);
-}
-
-template <bool OUTL, int BITS>
-static hipError_t launch_d(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
-    if (a.nw == 4) {
-        switch (a.rs_cap) {
-            case 1: return launch_dmr<4, 4, OUTL, BITS, 1>(a, mode, nblk, smem, st);
-            case 2: return launch_dmr<4, 4, OUTL, BITS, 2>(a, mode, nblk, smem, st);
-            case 3: return launch_dmr<4, 4, OUTL, BITS, 3>(a, mode, nblk, smem, st);
-            case 4: return launch_dmr<4, 4, OUTL, BITS, 4>(a, mode, nblk, smem, st);
-        }
-        return hipErrorInvalidValue;
-    }
-    switch (a.rs_cap) {           // row sets per block: a compile-time constant of the kernel
-        case 1: return depth >= 4 ? launch_dmr<8, 4, OUTL, BITS, 1>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 1>(a, mode, nblk, smem, st);
-        case 2: return depth >= 4 ? launch_dmr<8, 4, OUTL, BITS, 2>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 2>(a, mode, nblk, smem, st);
-        case 3: return depth >= 4 ? launch_dmr<8, 6, OUTL, BITS, 3>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 3>(a, mode, nblk, smem, st);
-        case 4: return depth >= 4 ? launch_dmr<8, 6, OUTL, BITS, 4>(a, mode, nblk, smem, st) : launch_dmr<8, 2, OUTL, BITS, 4>(a, mode, nblk, smem, st);
-    }
-    return hipErrorInvalidValue;
-}
-
-template <int BITS>
-static hipError_t launch_b(const V3Args& a, int mode, int nblk, size_t smem, int depth, hipStream_t st) {
-    return a.g.n_out > 0 ? launch_d<true, BITS>(a, mode, nblk, smem, depth, st) : launch_d<false, BITS>(a, mode, nblk, smem, depth, st);
-}
 
 static int env_int(const char* name) {
     const char* e = getenv(name);
@@ -130,7 +87,10 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     const int depth = f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 ? 4 : 2);
     const bool w3 = a.bits == 3;
     g_last_variant = a.m > 1 ? "gemv_v3_mb" : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
-    return w3 ? launch_b<3>(a, mode, a.nblk, smem, depth, st) : launch_b<4>(a, mode, a.nblk, smem, depth, st);
+    // plain launches (no run-time flag, one batch row): the instantiations without the flag paths (gemv_v3_plain.hip)
+    if (a.m <= 1 && (v3_flags(a) & (V3_F_PERCH | V3_F_XN | V3_F_SZN | V3_F_OWIL | V3_F_GATHER)) == 0)
+        return gemv_v3_dispatch_plain(a, mode, smem, depth, st);
+    return w3 ? launch_b<3, true>(a, mode, a.nblk, smem, depth, st) : launch_b<4, true>(a, mode, a.nblk, smem, depth, st);
 }
 
 // ---- host-side enumeration of every address the kernel can form for a configuration (no GPU involved).

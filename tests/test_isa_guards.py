@@ -85,10 +85,11 @@ def test_dx_v3_agpr_ring_is_untouched_by_compiler_code(gemm_asm):
     assert md.get("vgpr_spill_count", 0) == 0 and md.get("private_segment_fixed_size", 0) == 0, md
 
 
-def test_decode_gemv_kernels_do_not_spill(tmp_path_factory):
-    text = _asm(tmp_path_factory, "gemv_v3.hip")
+@pytest.mark.parametrize("src,at_least", [("gemv_v3.hip", 64), ("gemv_v3_plain.hip", 64)])
+def test_decode_gemv_kernels_do_not_spill(tmp_path_factory, src, at_least):
+    text = _asm(tmp_path_factory, src)
     names = re.findall(r"\.name:\s+(_ZN4qeft14gemv_v3_kernel\w+)", text)
-    assert len(names) >= 64
+    assert len(names) >= at_least
     bad = {}
     for n in set(names):
         md = _metadata(text, n)
