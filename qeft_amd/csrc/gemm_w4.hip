@@ -1439,19 +1439,25 @@ D3_RING_SET(3, 24, 25, 26, 27, 28, 29)
 
 // BITS = 3 (round 3): qw is the 3-bit extension layout; a loader lane owns the 12-byte record (row, 32-k chunk) of its tile
 // position and unpacks it into the same four 16-byte fp16 runs -- the dX of a 3-bit layer without an expansion pass.
-template <int BITS = 4>
+// MT = 4 (round 3): 128 (m) x 128 (k) tiles -- the same kernel for the sizes where 256-row tiles leave the chip short of blocks
+// (M = 1024 on K = 4096: 128 tiles of 256 rows against 256 of 128); a 16 KB dy stage, 4 DMA pieces per loader wave and stage,
+// barrier B after 2 of the 4 m-tile phases, two n-steps of the next tile's W fragments in each of the last two.
+template <int BITS = 4, int MT = 8>
 __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restrict__ dy, const uint8_t* __restrict__ qw,
                                                               const f16* __restrict__ scales, const f16* __restrict__ zeros,
                                                               const f16* __restrict__ ow, f16* __restrict__ dx, int M, int N,
                                                               int K, int G, int n_out, int NB) {
+    static_assert(MT == 8 || MT == 4, "256- or 128-row tiles");
+    constexpr int BMR = 32 * MT, AP = MT;                         // rows of the tile; dy pieces (1 KB) per loader wave and stage
+    constexpr int A_B = BMR * D3_BN * 2, WOFF = D3_ST * A_B;      // bytes of a dy stage; the two 16 KB fp16 weight tiles behind the ring
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through the k-tiles of one 256-row block of dy
+    // XCD-contiguous block order (blocks b, b + 8, .. share an L2): an XCD works through the k-tiles of one row block of dy
     const int nblk = gridDim.x, bq = nblk >> 3, br = nblk & 7, bx = blockIdx.x & 7;
     const int c = (bx < br ? bx * (bq + 1) : br * (bq + 1) + (bx - br) * bq) + (blockIdx.x >> 3);
-    const int bm0 = (c / NB) * D3_BM, kt = c % NB;
+    const int bm0 = (c / NB) * BMR, kt = c % NB;
     const int ntiles = N / D3_BN;              // >= 4 (launcher)
     const int kq = K - n_out;
     const bool outl_blk = kt * D3_BK >= kq;    // n_out % 128 == 0: a k-tile is INT4 or fp16 as a whole
@@ -1459,15 +1465,15 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
     if (wave >= 4) {
         // =========================================================== loader waves
         const int l = wave - 4;
-        uint32_t a_off[8];         // dy piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7)
+        uint32_t a_off[AP];        // dy piece p = 8 rows x 128 B: row 8p + lane/8, LDS chunk lane%8 holds global chunk (lane%8) ^ ((row >> 1) & 7)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (l * 8 + i) * 8 + (lane >> 3);
+        for (int i = 0; i < AP; ++i) {
+            const int row = (l * AP + i) * 8 + (lane >> 3);
             const int grow = min(bm0 + row, M - 1);
             a_off[i] = (uint32_t)grow * (uint32_t)N * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
         }
         auto stage_a = [&](int t) {
-            g3_dma_a8((const uint8_t*)dy + (size_t)t * (D3_BN * 2), a_off, lds0 + (uint32_t)(t & (D3_ST - 1)) * D3_A + (uint32_t)l * 8192u);
+            g3_dma_a((const uint8_t*)dy + (size_t)t * (D3_BN * 2), a_off, lds0 + (uint32_t)(t & (D3_ST - 1)) * A_B + (uint32_t)l * (AP * 1024u));
         };
         // weight role of the lane: row group 4 l + lane/16 of the tile's 16, piece p = lane % 16 of its 256 contiguous bytes
         // = row n & 3 = (p & 7) >> 1, 32-k chunk kc = 2 (p >> 3) + (p & 1) of the 128-k tile
@@ -1477,7 +1483,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
         const int kc = BITS == 3 ? (lane >> 4) : 2 * (pp >> 3) + (pp & 1);
         uint32_t w_dst[4];         // the lane's four 16-byte slots in the fp16 tile (+ buffer offset)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w_dst[j] = (uint32_t)(D3_WOFF + n_l * 256 + (((kc * 4 + j) ^ (n3 << 2) ^ n3) << 4));
+        for (int j = 0; j < 4; ++j) w_dst[j] = (uint32_t)(WOFF + n_l * 256 + (((kc * 4 + j) ^ (n3 << 2) ^ n3) << 4));
         auto sync = [&]() {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1531,7 +1537,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             using S2 = std::integral_constant<int, 2>;
             using S3 = std::integral_constant<int, 3>;
             auto steady = [&](int t, auto use, auto fill) {
-                asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + AP) : "memory");
                 sync();
                 pload(fill, t + 4);
                 dequant_store(use, (t + 1) & 1);
@@ -1542,7 +1548,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             };
             // the last three tiles: nothing left to issue.  first: the step before it was a steady one (11 younger operations)
             auto tail = [&](bool first, int t, auto use) {
-                if (first) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + AP) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 sync();
                 if (t + 1 < ntiles) dequant_store(use, (t + 1) & 1);
@@ -1551,12 +1557,12 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             };
             pload(S0{}, 0); pload(S1{}, 1); pload(S2{}, 2); pload(S3{}, 3);
             stage_a(0); stage_a(1); stage_a(2);
-            asm volatile("s_waitcnt vmcnt(33)" ::: "memory");            // tile 0's weights: 9 + 24 younger
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + 3 * AP) : "memory");            // tile 0's weights: 9 + 3 stages of dy pieces younger
             dequant_store(S0{}, 0);
-            asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // dy tile 0
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(2 * AP) : "memory");      // dy tile 0
             sync();
-            // t = 0: dy tile 1 landed <=> all but tile 2's 8 pieces
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // t = 0: dy tile 1 landed <=> all but tile 2's pieces
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");
             sync();
             pload(S0{}, 4);
             dequant_store(S1{}, 1);
@@ -1600,23 +1606,23 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
             };
             auto stage_w = [&](int t) {            // 4 DMA operations
                 const uint8_t* b = obase + (size_t)t * tile_stride;
-                const uint32_t dst = lds0 + D3_WOFF + (uint32_t)(t & 1) * D3_W + (uint32_t)l * 4096u;
+                const uint32_t dst = lds0 + WOFF + (uint32_t)(t & 1) * D3_W + (uint32_t)l * 4096u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g3_dma16(b, o_off[i], dst + i * 1024);
             };
             for (int t = 0; t < 6; ++t) touch(t);
             stage_w(0); stage_w(1);
             stage_a(0); stage_a(1); stage_a(2);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");            // dy tile 0 (and, older, both W tiles)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AP) : "memory");            // dy tile 0 (and, older, both W tiles)
             sync();
             for (int t = 0; t < ntiles; ++t) {
                 // dy tile t + 1: issued by iteration t - 2 (or the prologue); younger = iteration t - 1's 13 operations
-                if (t == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");
+                else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 + AP) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 sync();
-                // W tile t + 1: issued by iteration t - 1 ahead of its 8 dy pieces
-                if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                // W tile t + 1: issued by iteration t - 1 ahead of its dy pieces
+                if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 sync();
                 if (t + 3 < ntiles) {          // behind B(t), like the INT4 path's DMA
@@ -1633,9 +1639,9 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
 
     // =============================================================== compute waves
     const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[8];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
@@ -1648,7 +1654,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
     typedef short s4 __attribute__((ext_vector_type(4)));
     const int tq = (lane & 15) >> 2;
     const int tslot = wave * 4 + ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
-    const uint32_t w_rd = (uint32_t)(D3_WOFF + (32 * h + tq) * 256 + ((tslot ^ (tq << 2) ^ tq) << 4) + (lane & 1) * 8);
+    const uint32_t w_rd = (uint32_t)(WOFF + (32 * h + tq) * 256 + ((tslot ^ (tq << 2) ^ tq) << 4) + (lane & 1) * 8);
     auto tr_read = [&](uint32_t off) -> u32x2 {
         return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(uintptr_t)(lds0 + off)));
     };
@@ -1670,11 +1676,11 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
     // the forward kernel), 4 MFMAs, and in phases 4..7 (behind barrier B) one n-step of the next tile's W fragments.
     auto tile_body = [&](auto next_tag, int t, const u32x4 (&bc)[4], u32x4 (&bn)[4]) {
         constexpr bool NEXT = decltype(next_tag)::value;
-        const uint8_t* st = lds + (size_t)(t & (D3_ST - 1)) * D3_A;
-        const uint8_t* sn = lds + (size_t)((t + 1) & (D3_ST - 1)) * D3_A;
+        const uint8_t* st = lds + (size_t)(t & (D3_ST - 1)) * A_B;
+        const uint8_t* sn = lds + (size_t)((t + 1) & (D3_ST - 1)) * A_B;
         const int nbuf = (t + 1) & 1;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             u32x4 (&cur)[4] = (mt & 1) ? fb : fa;
             u32x4 (&nxt)[4] = (mt & 1) ? fa : fb;
             if (mt == 0) {
@@ -1682,18 +1688,22 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
                                                                acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (mt == 4) {
+            if (mt == MT / 2) {
                 __builtin_amdgcn_s_barrier();              // B(t): W tile t + 1 is in LDS
                 asm volatile("" ::: "memory");
             }
-            if (mt < 7) {
+            if (mt < MT - 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(st + a_rd[j] + (mt + 1) * 4096);
             } else if (NEXT) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) nxt[j] = *(const u32x4*)(sn + a_rd[j]);
             }
-            if (NEXT && mt >= 4) fetch_w(nbuf, mt - 4, bn[mt - 4]);
+            if (NEXT && mt >= MT / 2) {                    // the next tile's W fragments, spread over the phases behind barrier B
+                constexpr int PER = 8 / MT;                // n-steps per phase: 1 (8 phases) or 2 (4 phases)
+#pragma unroll
+                for (int jj = 0; jj < PER; ++jj) fetch_w(nbuf, (mt - MT / 2) * PER + jj, bn[(mt - MT / 2) * PER + jj]);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = mt == 0 ? 1 : 0; j < 4; ++j)
@@ -1733,7 +1743,7 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
     {
         uint8_t* const col = lds + (wave * 32 + r) * 2;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 *(f16*)(col + (mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * G3_YP) = (f16)acc[mt][e];
@@ -1743,8 +1753,8 @@ __global__ __launch_bounds__(512) void gemm_w4_dx_kernel_v3(const f16* __restric
     {
         const int ch = lane & 15;
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int row = wave * 64 + i * 4 + (lane >> 4), m = bm0 + row;
+        for (int i = 0; i < 2 * MT; ++i) {
+            const int row = wave * (8 * MT) + i * 4 + (lane >> 4), m = bm0 + row;
             if (m >= M) continue;
             *(u32x4*)(dx + (size_t)m * K + kt * D3_BK + ch * 8) = *(const u32x4*)(lds + row * G3_YP + ch * 16);
         }
@@ -1764,45 +1774,57 @@ int gemm_w4_dx_split(int M, int N, int K) {
 
 // bits == 3: qw is the 3-bit extension layout; only the loader-wave tier reads it (hipErrorNotSupported otherwise: the caller
 // expands to the 4-bit layout, qeft_expand_w3, and comes back with bits == 4)
-bool gemm_w3_dx_native(int M, int N, int K, int G, int n_out) {
-    const int mb = (M + D3_BM - 1) / D3_BM, kb = K / D3_BK;
+// Tile of the loader-wave dX kernel for a shape: 8 (256 rows), 4 (128 rows) or 0 (the older kernels).  Same counting of rounds of
+// blocks as the forward's choice: 256-row tiles from 224 tiles on at M >= 1024, or where 128-row tiles would need a second round;
+// 128-row tiles from 112 tiles on (M > 128).
+static int gemm_dx_v3_tile(int M, int K) {
+    const int kb = K / D3_BK, t8 = ((M + D3_BM - 1) / D3_BM) * kb, t4 = ((M + 127) / 128) * kb;
+    if (t8 >= 224 && M >= 1024) return 8;
+    if (M > 256 && t8 >= 129 && 1.7 * ((t8 + 255) / 256) < 1.0 * ((t4 + 255) / 256)) return 8;
+    if (t4 >= 112 && M > 128) return 4;
+    return 0;
+}
+static bool gemm_dx_v3_ok(int M, int N, int K, int G, int n_out) {
     return K % D3_BK == 0 && n_out % D3_BK == 0 && n_out < K && G % D3_BK == 0 && N % D3_BN == 0 && N >= 4 * D3_BN &&
-           (size_t)M * N * 2 < (1ull << 32) && (size_t)(N / 16) * ((K - n_out) / 128) * 768 < (1ull << 32) &&
-           (size_t)N * n_out * 2 < (1ull << 32) && mb * kb >= 224 && M >= 1024;
+           (size_t)M * N * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32) && (size_t)N * n_out * 2 < (1ull << 32);
+}
+bool gemm_w3_dx_native(int M, int N, int K, int G, int n_out) {
+    return gemm_dx_v3_ok(M, N, K, G, n_out) && (size_t)(N / 16) * ((K - n_out) / 128) * 768 < (1ull << 32) && gemm_dx_v3_tile(M, K) != 0;
+}
+
+template <int BITS>
+static hipError_t gemm_dx_v3_go(int tile, const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow, void* dx,
+                                int M, int N, int K, int G, int n_out, hipStream_t st) {
+    const int kb = K / D3_BK, mbt = (M + 32 * tile - 1) / (32 * tile);
+    const int smem = D3_ST * 32 * tile * D3_BN * 2 + 2 * D3_W;          // 163840 (256 rows) / 98304 (128 rows) bytes
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(mbt * kb), dim3(512), smem, st, (const f16*)dy, (const uint8_t*)qw, (const f16*)scales,
+                           (const f16*)zeros, (const f16*)ow, (f16*)dx, M, N, K, G, n_out, kb);
+        return hipGetLastError();
+    };
+    return tile == 8 ? go(gemm_w4_dx_kernel_v3<BITS, 8>) : go(gemm_w4_dx_kernel_v3<BITS, 4>);
 }
 
 hipError_t gemm_w4_dx_launch(const void* dy, const void* qw, const void* scales, const void* zeros, const void* ow,
                              void* dx, int M, int N, int K, int G, int n_out, hipStream_t st, void* workspace,
                              size_t workspace_bytes, int bits) {
+    const bool outl3 = ow && n_out > 0;
     if (bits == 3) {
-        const bool outl = ow && n_out > 0;
-        if (!gemm_w3_dx_native(M, N, K, G, outl ? n_out : 0)) return hipErrorNotSupported;
-        const int mb = (M + D3_BM - 1) / D3_BM, kb = K / D3_BK;
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_dx_kernel_v3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D3_SMEM);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(gemm_w4_dx_kernel_v3<3>, dim3(mb * kb), dim3(512), D3_SMEM, st, (const f16*)dy, (const uint8_t*)qw,
-                           (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (f16*)dx, M, N, K, G,
-                           outl ? n_out : 0, kb);
-        g_last_variant = "dx256_w3";
-        return hipGetLastError();
+        if (!gemm_w3_dx_native(M, N, K, G, outl3 ? n_out : 0)) return hipErrorNotSupported;
+        const int tile = gemm_dx_v3_tile(M, K);
+        g_last_variant = tile == 8 ? "dx256_w3" : "dx128v3_w3";
+        return gemm_dx_v3_go<3>(tile, dy, qw, scales, zeros, outl3 ? ow : nullptr, dx, M, N, K, G, outl3 ? n_out : 0, st);
     }
-    // 256 x 128 tiles with loader waves (gemm_w4_dx_kernel_v3) when they give (nearly) every CU a block: the M >= 2048 tier
-    // of a fine-tune step.  QEFT_DX_V3 = 0 / 1 forces the choice (A/B).
+    // Loader-wave tiles (gemm_w4_dx_kernel_v3): 256 x 128 when they give (nearly) every CU a block -- the M >= 2048 tier of a
+    // fine-tune step --, 128 x 128 below that (round 3).  QEFT_DX_V3 = 0 / 1 forces the choice (1: the 256-row tile) (A/B).
     {
         static const int force_v3 = getenv("QEFT_DX_V3") ? atoi(getenv("QEFT_DX_V3")) : -1;
-        const int mb = (M + D3_BM - 1) / D3_BM, kb = K / D3_BK;
-        const bool outl = ow && n_out > 0;
-        const bool ok3 = K % D3_BK == 0 && (!outl || n_out % D3_BK == 0) && G % D3_BK == 0 && N % D3_BN == 0 && N >= 4 * D3_BN &&
-                         (size_t)M * N * 2 < (1ull << 32) && (size_t)(N / 4) * K * 2 < (1ull << 32) &&
-                         (size_t)N * (outl ? n_out : 0) * 2 < (1ull << 32);
-        if (ok3 && (force_v3 == 1 || (force_v3 != 0 && mb * kb >= 224 && M >= 1024))) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_w4_dx_kernel_v3<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D3_SMEM);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(gemm_w4_dx_kernel_v3<4>, dim3(mb * kb), dim3(512), D3_SMEM, st, (const f16*)dy, (const uint8_t*)qw,
-                               (const f16*)scales, (const f16*)zeros, (const f16*)(outl ? ow : nullptr), (f16*)dx, M, N, K, G,
-                               outl ? n_out : 0, kb);
-            g_last_variant = "dx256";
-            return hipGetLastError();
+        const int tile = force_v3 == 1 ? 8 : force_v3 == 0 ? 0 : gemm_dx_v3_tile(M, K);
+        if (tile && gemm_dx_v3_ok(M, N, K, G, outl3 ? n_out : 0)) {
+            g_last_variant = tile == 8 ? "dx256" : "dx128v3";
+            return gemm_dx_v3_go<4>(tile, dy, qw, scales, zeros, outl3 ? ow : nullptr, dx, M, N, K, G, outl3 ? n_out : 0, st);
         }
     }
     // the 128-wide tile when it still gives every CU two blocks; smaller problems keep the 64-wide tile (twice the

@@ -226,3 +226,31 @@ def test_gemm_split_k_on_the_loader_wave_tile(m, n, k, r, g):
     assert rel_err(y, yref) < REL_TOL
     assert elem_err_ok(y, yref)
     assert np.array_equal(y, y2.cpu().numpy())          # ordered sum of the partials: run to run bit-identical
+
+
+@pytest.mark.parametrize("m,n,k,r,g,bits", [(1024, 4096, 4096, 128, 128, 4), (600, 448, 6144, 128, 128, 4), (513, 320, 6144, 0, 256, 4),
+                                            (1000, 11008, 4096, 128, 128, 4), (1024, 4096, 4096, 128, 128, 3), (530, 704, 6144, 128, 128, 3)])
+def test_dx_mid_m_tier_128_row_tiles(m, n, k, r, g, bits):
+    """dX on 128 x 128 loader-wave tiles (round 3): M = 1024 on K = 4096 was SLOWER than M = 2048 (128 tiles of 256 rows fell
+    back to the older kernels: 80 vs 72 us).  Whole and ragged M, every remainder class of the loader's weight ring (5 / 7 / 11 /
+    64 / 172 n-tiles), no outlier slice, group 256, the 3-bit stream; sampled columns vs the oracle, variant asserted."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, r, g, seed=m + n + bits, bits=bits)
+    t = layer_to_torch(bufs, DEV)
+    dy = (np.random.default_rng(n).standard_normal((m, n)) * 0.1).astype(np.float16)
+    dyt = torch.from_numpy(dy).to(DEV)
+    ow = t.get("oweight") if r else None
+    if bits == 3:
+        dx = qeft_cuda.gemm_3bit_dx(dyt, t["qweight"], t["scales"], t["scaled_zeros"], ow, k)
+    else:
+        dx = qeft_cuda.gemm_4bit_dx(dyt, t["qweight"], t["scales"], t["scaled_zeros"], ow)
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == ("dx128v3_w3" if bits == 3 else "dx128v3"), variant
+    w = O.dequant_dense(bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs.get("oweight") if r else None, g)
+    cols = np.unique(np.concatenate([np.arange(0, 64), np.arange(k - 192, k), np.random.default_rng(3).integers(0, k, 256)]))
+    ref = dy.astype(np.float64) @ w[:, cols].astype(np.float64)
+    dx = dx.cpu().numpy()
+    assert dx.shape == (m, k)
+    assert rel_err(dx[:, cols], ref) < REL_TOL
+    assert elem_err_ok(dx[:, cols], ref)

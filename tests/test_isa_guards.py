@@ -53,7 +53,12 @@ def test_dx_v3_agpr_ring_is_untouched_by_compiler_code(gemm_asm):
     """The ring lives in the LOADER waves (waves 4..7: `if (wave >= 4) { ... return; }`, one contiguous stretch of the kernel's
     text); the compute waves' MFMA accumulators may use the same register numbers in their own stretch.  Between the first and
     the last asm statement that names a ring register, no compiler-generated instruction may name an AGPR below 32."""
-    name, body = _kernel_body(gemm_asm, "_ZN4qeft20gemm_w4_dx_kernel_v3")
+    for name in sorted(set(re.findall(r"^(_ZN4qeft20gemm_w4_dx_kernel_v3\w*):", gemm_asm, re.M))):      # every instantiation (bits, tile rows)
+        _check_dx_ring(gemm_asm, name)
+
+
+def _check_dx_ring(gemm_asm, name):
+    _, body = _kernel_body(gemm_asm, name)
     agpr = re.compile(r"(?<![\w.])a(\d+|\[\d+:\d+\])(?![\w])")
     rows, in_asm = [], False                   # (in_asm, low AGPRs named, text)
     for ln in body.split("\n"):
