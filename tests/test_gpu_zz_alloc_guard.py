@@ -132,6 +132,15 @@ for (n, k, r, g, m) in [(7176, 384, 64, 64, 129), (3592, 512, 128, 128, 530)]:
     torch.cuda.synchronize()
     ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g)
     assert rel_err(y.cpu().numpy(), ref.astype(np.float64)) < 1e-3, ("gemm v3 128", n, k, r, g, m)
+for (n, k, r, g, m) in [(256, 3072, 128, 128, 530), (320, 3072, 0, 128, 513)]:       # the 128-row dX tile: 4 / 5 n-tiles, ragged M
+    b = O.make_layer(n, k, r, g, seed=n + m)
+    t = layer_to_torch(b, DEV)
+    dy = (np.random.default_rng(n).standard_normal((m, n)) * 0.1).astype(np.float16)
+    dx = qeft_cuda.gemm_4bit_dx(torch.from_numpy(dy).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    assert _lib.last_variant() == "dx128v3", _lib.last_variant()
+    torch.cuda.synchronize()
+    w = O.dequant_dense(b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, g)
+    assert rel_err(dx.cpu().numpy(), dy.astype(np.float64) @ w.astype(np.float64)) < 2e-3, ("dx128v3", n, k, r, g, m)
 for (n, k, r, g, m, gather) in [(16, 256, 128, 128, 1, True), (16, 256, 128, 128, 7, True), (48, 384, 0, 128, 5, False),
                                 (16 * 257, 256, 128, 128, 3, False), (32, 4096, 128, 4096, 2, True), (16, 11008, 128, 128, 7, False)]:
     gemv(n, k, r, g, m, gather=gather)
