@@ -713,6 +713,11 @@ def main():
                 extras["prefill_2048"] = pre
                 extras["prefill_mid_m"] = {"per_shape": mid_m_records(dev), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
                                            "note": "forward GEMM (fused outlier slice) below the M = 2048 tier, 4 weight sets cycled"}
+                # the same step at M = 1024 (a shorter batch: the 128-row loader-wave tiles of round 3, forward and dX)
+                ft1024 = gemm_records(dev, m=1024, reps=15)[1]
+                extras["finetune_step_m1024"] = {"M": 1024, "per_shape": [
+                    {k: r[k] for k in ("shape", "forward_us", "dx_us", "dow_us", "step_us", "w3_step_us", "step_TFLOPs", "variants")}
+                    for r in ft1024]}
                 extras["finetune_step"] = {"M": 2048, "per_shape": ft_recs,
                                            "note": "forward + dX + d(oweight) of one QuantLinear, oweight trainable (qlinear.py:13-44); dx_dow_overlapped_us: dX with d(oweight) on a second stream; w3_*: the same step of a 3-bit layer on the 3-bit stream (no expansion pass)"}
             except Exception as e:
