@@ -22,6 +22,7 @@ CHILD = r'''
 import sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np, torch
+torch.manual_seed(20261004)
 from oracle import qeft_oracle as O
 from util import layer_to_torch, rel_err
 from qeft_amd import qeft_cuda, _lib
@@ -155,7 +156,9 @@ want = torch.cat([rr[..., :64].float() * cc[:, None] - rr[..., 64:].float() * ss
 _lib.check(lib.qeft_rope_rows(rr.data_ptr(), cc.data_ptr(), ss.data_ptr(), 3, 1, 128, st))
 torch.cuda.synchronize()
 hn = (hh * torch.rsqrt((hh ** 2).mean() + 1e-5)).half()
-assert (lo.float() - hn.float() @ ww.float().t()).abs().max().item() < 2e-2 and torch.equal(rr, want)
+assert (lo.float() - hn.float() @ ww.float().t()).abs().max().item() < 2e-2
+# (the kernel's a * c - b * s may be one fused multiply-add where torch rounds two products: equal up to one fp16 ulp on random data)
+assert (rr.float() - want.float()).abs().max().item() <= 2e-3 * max(1.0, want.float().abs().max().item())
 print("GUARD-OK")
 '''
 
