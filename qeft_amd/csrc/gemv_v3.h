@@ -69,6 +69,18 @@ struct V3Geom {
     int K, n_out, nsteps, nfull, ngroups, nsets;   // nsets = N / 16
 };
 
+// LAB ONLY (-DQEFT_LAB, tools/gemv_v3_lab.hip): the NEXT launch's ring head, for the cross-launch L2 warm-up experiment of round 3
+// (gemv_v3_kernel step 0; measured, not adopted: DESIGN.md section 6, profiles/r03_gemv_warm_lab.txt).  qw == NULL: nothing to warm.
+struct V3Prefetch {
+    const uint8_t* qw;      // the next launch's packed weights
+    uint32_t set_bytes;     // bytes of one 16-row set of it
+    uint32_t seg_stride;    // bytes between a set's segments (4-bit: the four row groups, K' * 2 apart; 3-bit: one segment)
+    uint32_t geom;          // nblk' | rsc' << 16 | log2(1 KB pieces per segment) << 20 | log2(segments per set) << 24
+    uint32_t sets;          // sets_q' | sets_r' << 16
+    uint32_t stride;        // THIS launch's grid rounded down to a multiple of 8 (block b also warms next-launch block b + stride)
+    uint32_t pace;          // pieces in flight (8 / 16 / 32 / 63) | start delay << 8 (units of ~1000 clocks; lab)
+};
+
 struct V3Args {
     const f16* x;           // [K] fp16, consumed as it is (xn_gamma == NULL), or the fp32 vector h [K] (xn_gamma != NULL)
     const f16* xn_gamma;    // optional: x is fp32 h and the launch itself stages fp16(h * xn_gamma) and applies rsqrt(mean h^2 + eps)
@@ -98,6 +110,9 @@ struct V3Args {
     const int* ids;         // optional reorder_ids int32 [K]: the launch consumes x[:, ids]
     int m;                  // batch rows 1..7 (0 is taken as 1); x is [m][K], y [m][N]; m > 1: PLAIN, no residual / ssq_in / xn
     int nw;                 // waves per block chosen by the launcher (LDS sizing)
+#if defined(QEFT_LAB)
+    V3Prefetch pf;          // the next launch's ring head (warm-up experiment)
+#endif
 };
 
 // What the kernel receives.  The first 16 dwords of the kernel-argument segment -- the four operand pointers and the
@@ -117,9 +132,16 @@ struct V3Tail {
     const int* ids;
     int n_out, nsteps, nsets, n_ssq_in;
     float eps;
+#if defined(QEFT_LAB)
+    V3Prefetch pf;
+#endif
 };
 inline V3Tail v3_tail(const V3Args& a) {
+#if defined(QEFT_LAB)
+    return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.ids, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps, a.pf};
+#else
     return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.ids, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps};
+#endif
 }
 inline uint32_t v3_flags(const V3Args& a) {
     const int m = a.m > 0 ? a.m : 1;
@@ -147,7 +169,7 @@ __host__ __device__ constexpr size_t v3_red_bytes(int rs_cap, int m = 1, int nw 
     return m > 1 ? ((size_t)rs_cap * nw * 8 * 16 * 4 + 1023) / 1024 * 1024 : ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024;
 }
 struct V3Lds {              // byte offsets of the regions inside the block's dynamic LDS
-    uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, total;
+    uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, pfl, total;
 };
 __host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_cap, int m, int nw, bool xn, bool szn, bool gather) {
     V3Lds L;
@@ -163,6 +185,10 @@ __host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_ca
     L.szraw = o; o += szn ? 2u * rs_cap * v3_szraw_bytes(ngroups) : 0u;                     // [2 arrays][rs_cap][groups][16] fp16
     L.idsl = o; o += gather ? (uint32_t)v3_xf_bytes(K) : 0u;                                // reorder_ids int32 [K]
     L.xraw = o; o += gather ? (uint32_t)m * v3_x_bytes(K) : 0u;                             // x rows before the gather
+    L.pfl = o;                                                                              // (lab) landing pad of the warm-up loads, never read
+#if defined(QEFT_LAB)
+    o += 4096;
+#endif
     L.total = o;
     return L;
 }
@@ -245,7 +271,29 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// N consecutive 1 KB pieces (N = 1, 2, 4) from gsrc, gsrc + 1024, .. by ONE asm statement (the instruction offset moves the
+// global and the LDS address alike): the warming wave's unit of work -- a wave issues an instruction every ~5 clocks at best,
+// so its loop must be a handful of instructions per piece
+template <int N> __device__ __forceinline__ void v3_dma16_run(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    if constexpr (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        v3_dma16(gsrc, lds_dst);
+}
+
 // In-kernel time stamps of the lab build (tools/gemv_v3_lab.hip, -DQEFT_LAB, ABL & 8); compiled out of the product
+// (the lab's blocks may carry one extra wave, the warming wave of the round-3 experiment)
+#if defined(QEFT_LAB)
+#define V3_LAUNCH_THREADS(nw) (((nw) + 1) * 64)
+#else
+#define V3_LAUNCH_THREADS(nw) ((nw) * 64)
+#endif
 #if defined(QEFT_LAB)
 #define V3_STAMP(i) do { if (ABL & 8) ts[i] = wall_clock64(); } while (0)
 #else
@@ -290,7 +338,7 @@ __host__ __device__ constexpr int v3_unroll_steps(int D, int RSC) {
 // FL: the run-time flags (V3_F_*: per-channel scales, consumer-side norm, checkpoint-layout operands, gather) are honoured; false
 //     for the plain launches of the decode engine, which then carry no trace of those paths.
 template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1, bool FL = true>
-__global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
+__global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
     static_assert(BITS == 4 || BITS == 3, "4-bit checkpoint layout or the 3-bit extension layout (oracle: pack_w3)");
@@ -349,6 +397,60 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
     long long ts[7] = {0, 0, 0, 0, 0, 0, 0};    // ABL & 8: entry, ring issued, staging landed (barrier), steps done, (end), all waves done (barrier), values ready
 #endif
     V3_STAMP(0);
+
+#if defined(QEFT_LAB)
+    // ---- 0. LAB ONLY: the WARMING wave (launched as wave NW only when a.pf.qw is set): the cross-launch L2 warm-up experiment.
+    //         The weights of the NEXT launch do not depend on this one, but its first loads cannot be issued before it starts:
+    //         they pay a full HBM round trip behind the launch boundary while HBM idles.  Here one extra wave per block pulls
+    //         the next launch's RING HEAD (the first D loads of each of its waves: V3Prefetch) -- that of the next launch's
+    //         block with the same physical id, i.e. on the same XCD under the round-robin placement, the same L2 -- in whole
+    //         1 KB pieces by LDS-DMA into a landing pad nobody reads.  Measured (profiles/r03_gemv_warm_lab.txt): the follower
+    //         does start 0.7-0.9 us earlier (its staging barrier falls at 1.2 instead of 2.0-2.8 us), but the warming bytes
+    //         are moved, not saved, and cost the warming launch as much or more than they save the follower: -0.5 us per launch
+    //         on a chain of down_proj launches, +0.0 on o_proj, +0.3 on q|k|v, and +0.1 .. +1.2 us per launch on the engine's
+    //         real chain (where a 459-block gate|up launch also shifts the round-robin placement by 3 XCDs, so its
+    //         follower misses).  Issued from the streaming waves instead (behind their loop, or in front of their last round)
+    //         the same loads held every block's final barrier back by 1.2 us.  NOT in the product.
+    if (wave == NW) {
+        __builtin_amdgcn_s_barrier();                                                               // step 3
+        if (XN || GATHER || SZN) __builtin_amdgcn_s_barrier();                                      // step 3b
+        // (the descriptor into registers ONCE: behind an asm with a memory clobber hipcc re-reads kernel arguments from memory,
+        //  ~450 clocks per piece -- the first version of this loop ran at 4 GB/s per wave)
+        const uint8_t* const pq = a.pf.qw;
+        const uint32_t geom = a.pf.geom, setb = a.pf.set_bytes, segs = a.pf.seg_stride, sets2 = a.pf.sets, stride = a.pf.stride, pace = a.pf.pace;
+        asm volatile("" ::"s"(pq), "s"(geom), "s"(setb), "s"(segs), "s"(sets2), "s"(stride), "s"(pace));
+        const uint32_t nblk2 = geom & 0xffffu, rsc2 = (geom >> 16) & 15u, pps = 1u << ((geom >> 20) & 15u), sps = 1u << ((geom >> 24) & 15u);
+        const uint32_t q2 = sets2 & 0xffffu, r2 = sets2 >> 16, bid = blockIdx.x;
+        const uint32_t pad = __builtin_amdgcn_readfirstlane(lds0 + L.pfl);
+        for (uint32_t d = (pace >> 8) & 0xffu; d > 0; --d) __builtin_amdgcn_s_sleep(16);            // (lab knob: start later)
+        const uint32_t deep = pace & 0xffu;
+        for (uint32_t bb = bid, jj = 0; bb < nblk2 && jj < 2; bb += stride, ++jj) {                 // the next launch's blocks this block warms
+            int set0n, cntn;
+            v3_block_sets(v3_xcd_block((int)bb, (int)nblk2), (int)q2, (int)r2, set0n, cntn);
+            if (cntn > (int)rsc2) cntn = (int)rsc2;
+            for (int rs = 0; rs < cntn; ++rs) {
+                const uint8_t* const pset = pq + (size_t)(set0n + rs) * setb + (size_t)lane * 16u;
+                for (uint32_t sg = 0; sg < sps; ++sg) {
+                    const uint8_t* p = pset + (size_t)sg * segs;
+                    if (pps >= 4) {
+                        for (uint32_t pc = 0; pc < pps; pc += 4) v3_dma16_run<4>(p + (size_t)pc * 1024u, pad);
+                    } else if (pps == 2) {
+                        v3_dma16_run<2>(p, pad);
+                    } else {
+                        v3_dma16_run<1>(p, pad);
+                    }
+                    if (deep <= 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (deep <= 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (deep <= 32) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(55)" ::: "memory");       // (the counter holds 63; a segment is at most 8 pieces)
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                                               // step 5
+        return;
+    }
+#endif
 
     // ---- 1. staging by LDS-DMA.  x: the waves take pieces w, w + NW, ..; per row set the scale words (piece j = wave) and
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
@@ -760,6 +862,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
                 a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5];
                 a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6];
                 a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+                a.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15;      // HW_REG_XCC_ID
             }
         }
 #endif
@@ -796,6 +899,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_v3_kernel(const uint8_t* qw, con
             a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5];
             a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6];
             a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
+            a.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15;      // HW_REG_XCC_ID
         }
     }
 #endif

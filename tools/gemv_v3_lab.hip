@@ -68,6 +68,23 @@ static int qeft_lab_blocks(int nsets) {     // gemv_v3_blocks (gemv_v3.hip)
     return nblk;
 }
 struct Kind { const char* name; int n, k, mode; bool ssq, res; };
+// the next launch's ring head (gemv_v3_prefetch_plan of gemv_v3.hip, with the lab's own geometry)
+static V3Prefetch lab_pf(const void* qw, int n, int k, int nblk, int nw, int D, int mult, int pace) {
+    V3Prefetch p{};
+    const int nsets = n / 16, rsc = (nsets + nblk - 1) / nblk, nfull = (k - 128) / 128;
+    int head = nw * ((D + rsc - 1) / rsc) * mult;
+    if (head > nfull) head = nfull;
+    int lg = 0;
+    while ((1 << lg) < (head + 3) / 4 && (2 << lg) <= k / 512) ++lg;
+    p.qw = (const uint8_t*)qw;
+    p.set_bytes = (uint32_t)k * 8u;
+    p.seg_stride = (uint32_t)k * 2u;
+    p.geom = (uint32_t)nblk | ((uint32_t)rsc << 16) | ((uint32_t)lg << 20) | (2u << 24);
+    p.sets = (uint32_t)(nsets / nblk) | ((uint32_t)(nsets % nblk) << 16);
+    p.stride = (nblk & ~7) ? (uint32_t)(nblk & ~7) : (1u << 30);
+    p.pace = (uint32_t)pace;
+    return p;
+}
 struct Case { std::string label; double bytes; int L; std::function<void(int)> f; std::vector<float> us; };
 static std::vector<Case> g_cases;
 struct Bufs { void *qw, *szp, *ow; };
@@ -76,7 +93,7 @@ template <int NW, int D, int MODE, int ABL, int RSC>
 static void launch_r(const V3Args& a, int nblk, size_t smem) {
     auto kern = gemv_v3_kernel<NW, D, true, MODE, ABL, 4, 1, RSC>;
     if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, V3_KERNEL_ARGS(a));
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64 + (a.pf.qw ? 64 : 0)), smem, 0, V3_KERNEL_ARGS(a));
 }
 // the lab's four launch kinds have 3 (q|k|v, gate|up) or 1 (o_proj, down_proj) row sets per block under the product's block rule
 template <int NW, int D, int MODE, int ABL>
@@ -87,7 +104,7 @@ static void launch(const V3Args& a, int nblk, size_t smem) {
 }
 
 template <int NW, int D, int ABL>
-static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk) {
+static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk, int pfmult = 0, int pace = 8) {
     const int nsets = kd.n / 16;
     if (nblk > nsets) nblk = nsets;
     if ((nsets + nblk - 1) / nblk > V3_MAX_RS) { printf("    (skip: %d blocks need > %d sets per block)\n", nblk, V3_MAX_RS); return; }
@@ -100,15 +117,16 @@ static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h3
     a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
     a.y = (f16*)y;
     const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
-    auto f = [a, &B, &kd, nblk, smem](int l) {
+    auto f = [a, &B, &kd, nblk, smem, pfmult, pace](int l) {
         V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
+        if (pfmult > 0) b.pf = lab_pf(B[(l + 1) % B.size()].qw, kd.n, kd.k, nblk, NW, D, pfmult, pace);     // the next launch of the cycle
         if (kd.mode == V3_MODE_PAIR) { if constexpr (NW <= 8) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); }
         else launch<NW, D, V3_MODE_PLAIN, ABL>(b, nblk, smem);
     };
     if (kd.mode == V3_MODE_PAIR && NW > 8) return;
     const double bytes = (double)kd.n * (kd.k - 128) / 2 + 2.0 * (kd.k / 128) * kd.n * 2 + (double)kd.n * 128 * 2 + 2 * kd.k + 2 * kd.n;
     char label[96];
-    snprintf(label, sizeof label, "%-4s NW=%2d D=%d blocks=%4d ABL=%2d", kd.name, NW, D, nblk, ABL);
+    snprintf(label, sizeof label, "%-4s NW=%2d D=%d blocks=%4d ABL=%2d warm=%d pace=%4d", kd.name, NW, D, nblk, ABL, pfmult, pace);
     g_cases.push_back(Case{label, bytes, (int)B.size(), f, {}});
 }
 // every registered case timed `rounds` times, the cases interleaved (box-level drift hits all of them alike); min and median
@@ -125,8 +143,8 @@ static void measure_cases(int rounds) {
 }
 
 // ABL = 8: time stamps of wave 0 of every block (100 MHz ticks) -> where a launch's time goes
-template <int NW, int D>
-static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk) {
+template <int NW, int D, int ABLX = 0>
+static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk, int pfmult = 0, int pace = 8) {
     const int nsets = kd.n / 16;
     V3Args a{};
     a.x = (const f16*)x;
@@ -144,14 +162,15 @@ static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, voi
         for (int l = 0; l < 6; ++l) {
             V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
             b.dbg = dbg + (size_t)l * nblk * 8;
+            if (pfmult > 0) b.pf = lab_pf(B[(l + 1) % 6].qw, kd.n, kd.k, nblk, NW, D, pfmult, pace);
             if (l == 0 && warm == 2) CK(hipEventRecord(e0, 0));
-            if (kd.mode == V3_MODE_PAIR) launch<NW, D, V3_MODE_PAIR, 8>(b, nblk, smem); else launch<NW, D, V3_MODE_PLAIN, 8>(b, nblk, smem);
+            if (kd.mode == V3_MODE_PAIR) launch<NW, D, V3_MODE_PAIR, 8 | ABLX>(b, nblk, smem); else launch<NW, D, V3_MODE_PLAIN, 8 | ABLX>(b, nblk, smem);
         }
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    printf("  %-4s NW=%2d D=%d blocks=%4d: %.2f us per launch (6 back to back); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, ms * 1e3 / 6);
+    printf("  %-4s NW=%2d D=%d blocks=%4d warm=%d pace=%d: %.2f us per launch (6 back to back); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, pfmult, pace, ms * 1e3 / 6);
     long long prev_end = 0;
     for (int l = 0; l < 6; ++l) {
         long long t0 = 1LL << 62, mx[7] = {0, 0, 0, 0, 0, 0, 0}, mn[7];
@@ -168,6 +187,8 @@ static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, voi
                (mn[3] - t0) / 100.0, (mx[3] - t0) / 100.0, (mn[4] - t0) / 100.0, (mx[4] - t0) / 100.0);
         printf(" | tail per block: wait for the block's waves %.2f, epilogue math %.2f, store + ack %.2f", tail[0], tail[1], tail[2]);
         if (l) printf(" | gap since previous end %.2f", (t0 - prev_end) / 100.0);
+        printf(" | XCD of blocks 0..9:");
+        for (int b = 0; b < 10 && b < nblk; ++b) printf(" %lld", h[((size_t)l * nblk + b) * 8 + 7]);
         printf("\n");
         prev_end = mx[4];
     }
@@ -214,6 +235,29 @@ int main() {
         printf("%s: n=%d k=%d\n", kd.name, kd.n, kd.k);
         const int nsets = kd.n / 16;
         const int nb = (splitk && kd.n == 8192) ? 512 : qeft_lab_blocks(nsets);
+        if (getenv("LAB_PF")) {       // the cross-launch L2 warm-up (gemv_v3.h step 0): off / on at 8, 4, 2 pieces in flight / started later / twice the head
+            auto pf_cases = [&](auto dtag) {
+                constexpr int D = decltype(dtag)::value;
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 0);
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 8);
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 16);
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 32);
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 64);
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 64 | (2 << 8));
+                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 2, 64);
+                measure_cases(7);
+                timeline<8, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 0);
+                timeline<8, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 64);
+                timeline<8, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 16);
+            };
+            if (kd.mode == V3_MODE_PAIR) printf("  (skipped)\n");
+            else if (kd.n == 12288) pf_cases(std::integral_constant<int, 6>{});
+            else if (kd.k == 4096) pf_cases(std::integral_constant<int, 2>{});
+            else pf_cases(std::integral_constant<int, 4>{});
+            for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
+            (void)hipFree(x); (void)hipFree(y);
+            continue;
+        }
         run<8, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
