@@ -456,44 +456,48 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
     //         wait for until the barrier below.  (What only the epilogue reads is requested behind the ring, step 2b.)
     const int PX = XB >> 10, SPS = SZB >> 10;
-    if (ABL & 16) {
-        // lab: no staging at all (the results are garbage) -- what the whole staging prologue costs
-    } else if (!XN) {
-        // (a gathering launch stages the rows as they are into xraw; step 3b writes xs)
-        const uint32_t xdst = lds0 + (GATHER ? L.xraw : L.xs), xstr = GATHER ? (uint32_t)XB : (uint32_t)XS;
-        for (int i = 0; i < m; ++i)
-            for (int p = wave; p < PX; p += NW)
-                v3_dma16(xptr + (size_t)i * G.K * 2 + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(xdst + (uint32_t)i * xstr + ((uint32_t)p << 10)));
-    } else {               // fp32 h (2 PX pieces) and its gamma (PX pieces) go to their own regions; xs is written in step 3b
-        const int PF = v3_xf_bytes(G.K) >> 10;
-        for (int p = wave; p < PF + PX; p += NW) {
-            if (p < PF)
-                v3_dma16(xptr + v3_xf_off(G, p, lane), __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xf32 + ((uint32_t)p << 10)));
-            else
-                v3_dma16((const uint8_t*)xn_gamma + v3_x_off(G, p - PF, lane),
-                         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xg + ((uint32_t)(p - PF) << 10)));
-        }
-    }
     const int SRB = v3_szraw_bytes(G.ngroups), SPR = SRB >> 10;
-    if (!(ABL & 16)) {
-#pragma unroll
-        for (int rs = 0; rs < RSC; ++rs) {
-            const int set = set_of(rs);
-            if (!SZN) {
-                for (int j = wave; j < SPS; j += NW)
-                    v3_dma16(szp + v3_sz_off(G, set, j, lane), __builtin_amdgcn_readfirstlane(lds0 + L.szl + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
-            } else {        // checkpoint layout: scales (array 0, the szp slot) and scaled_zeros (array 1, the xn_gamma slot), packed in step 3b
-                for (int t = wave; t < 2 * SPR; t += NW) {
-                    const int arr = t >= SPR ? 1 : 0, j = t - arr * SPR;
-                    v3_dma16((arr ? (const uint8_t*)xn_gamma : szp) + v3_szn_off(G, set, j, lane),
-                             __builtin_amdgcn_readfirstlane(lds0 + L.szraw + (uint32_t)(arr * RSC + rs) * SRB + ((uint32_t)j << 10)));
-                }
+    auto stage_all = [&]() {
+        if (ABL & 16) {
+            // lab: no staging at all (the results are garbage) -- what the whole staging prologue costs
+        } else if (!XN) {
+            // (a gathering launch stages the rows as they are into xraw; step 3b writes xs)
+            const uint32_t xdst = lds0 + (GATHER ? L.xraw : L.xs), xstr = GATHER ? (uint32_t)XB : (uint32_t)XS;
+            for (int i = 0; i < m; ++i)
+                for (int p = wave; p < PX; p += NW)
+                    v3_dma16(xptr + (size_t)i * G.K * 2 + v3_x_off(G, p, lane), __builtin_amdgcn_readfirstlane(xdst + (uint32_t)i * xstr + ((uint32_t)p << 10)));
+        } else {               // fp32 h (2 PX pieces) and its gamma (PX pieces) go to their own regions; xs is written in step 3b
+            const int PF = v3_xf_bytes(G.K) >> 10;
+            for (int p = wave; p < PF + PX; p += NW) {
+                if (p < PF)
+                    v3_dma16(xptr + v3_xf_off(G, p, lane), __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xf32 + ((uint32_t)p << 10)));
+                else
+                    v3_dma16((const uint8_t*)xn_gamma + v3_x_off(G, p - PF, lane),
+                             __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xg + ((uint32_t)(p - PF) << 10)));
             }
-            if (OUTL && wave >= NW - 4)
-                v3_dma16(ow + (OWIL ? v3_owil_off(set, wave - (NW - 4), lane) : v3_ow_off(set, wave - (NW - 4), lane)),
-                         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - (NW - 4)) << 10)));
         }
-    }
+        if (!(ABL & 16)) {
+    #pragma unroll
+            for (int rs = 0; rs < RSC; ++rs) {
+                const int set = set_of(rs);
+                if (!SZN) {
+                    for (int j = wave; j < SPS; j += NW)
+                        v3_dma16(szp + v3_sz_off(G, set, j, lane), __builtin_amdgcn_readfirstlane(lds0 + L.szl + (uint32_t)rs * SZB + ((uint32_t)j << 10)));
+                } else {        // checkpoint layout: scales (array 0, the szp slot) and scaled_zeros (array 1, the xn_gamma slot), packed in step 3b
+                    for (int t = wave; t < 2 * SPR; t += NW) {
+                        const int arr = t >= SPR ? 1 : 0, j = t - arr * SPR;
+                        v3_dma16((arr ? (const uint8_t*)xn_gamma : szp) + v3_szn_off(G, set, j, lane),
+                                 __builtin_amdgcn_readfirstlane(lds0 + L.szraw + (uint32_t)(arr * RSC + rs) * SRB + ((uint32_t)j << 10)));
+                    }
+                }
+                if (OUTL && wave >= NW - 4)
+                    v3_dma16(ow + (OWIL ? v3_owil_off(set, wave - (NW - 4), lane) : v3_ow_off(set, wave - (NW - 4), lane)),
+                             __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)owl + (uint32_t)rs * 4096u + ((uint32_t)(wave - (NW - 4)) << 10)));
+            }
+        }
+    };
+    // ABL & 256 (lab): the ring first, the staging pieces behind it (the staging wait then covers the ring's first loads too)
+    if (!(ABL & 256)) stage_all();
 
     // ---- 2. weight stream: ring of D loads per wave, branch-free, oldest first.  The wave's work is the sequence
     //         c = 0 .. nsw * RSC - 1 of (step wave + NW (c / RSC), row set c % RSC): STEP-major, so the x fragments and the bias
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         __builtin_amdgcn_sched_barrier(0);
     });
 
+    if (ABL & 256) stage_all();
     asm volatile("" ::"s"(G.nsteps), "s"(ssq_n), "s"(ssq_in), "s"(residual), "s"(gamma_out), "s"(eps), "s"(bias), "s"(yout), "s"(y32),
                  "s"(ynorm), "s"(ssq_out), "s"(idsp));
     V3_STAMP(1);
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // ---- 3. staged data complete: this wave's pieces are older than its D ring loads
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 256) ? 0 : D) : "memory");
     // ---- 2b. epilogue-only operands, requested BEHIND the ring (they must not delay the weight stream): wave 1 the
     //          residual / gamma_out values of the block's rows, waves 2 and 3 the producer's partial sums of squares.  They
     //          complete before the vmcnt(0) every wave executes in front of the final barrier.

@@ -170,7 +170,7 @@ static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, voi
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    printf("  %-4s NW=%2d D=%d blocks=%4d warm=%d pace=%d: %.2f us per launch (6 back to back); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, pfmult, pace, ms * 1e3 / 6);
+    printf("  %-4s NW=%2d D=%d blocks=%4d ABL=%d warm=%d pace=%d: %.2f us per launch (6 back to back); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, ABLX, pfmult, pace, ms * 1e3 / 6);
     long long prev_end = 0;
     for (int l = 0; l < 6; ++l) {
         long long t0 = 1LL << 62, mx[7] = {0, 0, 0, 0, 0, 0, 0}, mn[7];
@@ -235,6 +235,23 @@ int main() {
         printf("%s: n=%d k=%d\n", kd.name, kd.n, kd.k);
         const int nsets = kd.n / 16;
         const int nb = (splitk && kd.n == 8192) ? 512 : qeft_lab_blocks(nsets);
+        if (getenv("LAB_RF")) {       // ring first (ABL & 256): the weight ring issued in front of the staging pieces
+            auto rf_cases = [&](auto nwtag, auto dtag) {
+                constexpr int NWc = decltype(nwtag)::value, D = decltype(dtag)::value;
+                run<NWc, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+                run<NWc, D, 256>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+                measure_cases(9);
+                timeline<NWc, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+                timeline<NWc, D, 256>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+            };
+            if (kd.mode == V3_MODE_PAIR) rf_cases(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+            else if (kd.n == 12288) rf_cases(std::integral_constant<int, 8>{}, std::integral_constant<int, 6>{});
+            else if (kd.k == 4096) rf_cases(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+            else rf_cases(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
+            for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
+            (void)hipFree(x); (void)hipFree(y);
+            continue;
+        }
         if (getenv("LAB_PF")) {       // the cross-launch L2 warm-up (gemv_v3.h step 0): off / on at 8, 4, 2 pieces in flight / started later / twice the head
             auto pf_cases = [&](auto dtag) {
                 constexpr int D = decltype(dtag)::value;
