@@ -125,6 +125,60 @@ const char* qeft_error_string(int code) {
     }
 }
 
+// m batch rows (1..16 per launch) through the v3 decode GEMV on the operands as the CHECKPOINT holds them (gemv_v3.h): the
+// scales staged raw and packed in LDS (or the sz_packed shadow when the caller has one), the outlier slab from
+// oweight_interleaved (the gemv entries) or the plain oweight [n, r] (the GEMM entries), the o_proj gather inside the
+// launch, the batch rows as A rows of the same MFMAs.  A batch whose x rows do not fit the block's LDS goes in several
+// launches, split evenly; more than `max_launches` of them: not taken (V3_NOT_TAKEN), like a shape the kernel does not serve.
+constexpr int V3_NOT_TAKEN = -1000;
+// launches v3_rows would make for m rows of this shape on checkpoint-layout operands (0: the kernel does not serve it)
+static int v3_rows_launches(int m, int n, int k, int group_size, int n_out) {
+    if (m < 1 || !v3_route_enabled() || n <= 0 || n % 16 != 0 || !qeft::gemv_v3_ok(k, group_size, n_out)) return 0;
+    qeft::V3Args v{};
+    v.g.K = k;
+    v.g.n_out = n_out;
+    v.g.nsteps = k / 128;
+    v.g.nfull = (k - n_out) / 128;
+    v.g.ngroups = group_size == k ? 1 : k / 128;
+    v.g.nsets = n / 16;
+    const int mmax = qeft::gemv_v3_max_rows(v, m);
+    return mmax < 1 ? 0 : (m + mmax - 1) / mmax;
+}
+constexpr int kGemmRowsOnGemvLaunches = 2;      // the GEMM entries put up to 16 rows on the decode GEMV if that takes two launches at most
+static int v3_rows(const void* x, const void* qweight, const void* scales, const void* scaled_zeros, const void* oweight_plain,
+                   const void* oweight_il, const void* bias, const int* reorder_ids, const void* sz_packed, void* y, int m, int n,
+                   int k, int group_size, int n_out, qeft_stream_t stream, int max_launches) {
+    if (!v3_route_enabled() || n % 16 != 0 || !qeft::gemv_v3_ok(k, group_size, n_out) || !aligned16(scales) || !aligned16(scaled_zeros) ||
+        (reorder_ids && !aligned16(reorder_ids)))
+        return V3_NOT_TAKEN;
+    qeft::V3Args v{};
+    v.g.K = k;
+    v.g.n_out = n_out;
+    v.g.nsteps = k / 128;
+    v.g.nfull = (k - n_out) / 128;
+    v.g.ngroups = group_size == k ? 1 : k / 128;
+    v.g.nsets = n / 16;
+    v.qw = (const uint8_t*)qweight;
+    v.szp = (const uint8_t*)sz_packed;
+    v.scales = (const qeft::f16*)scales;
+    v.zeros = (const qeft::f16*)scaled_zeros;
+    v.ow = (const uint8_t*)oweight_plain;
+    v.ow_il = (const uint8_t*)oweight_il;
+    v.bias = (const qeft::f16*)bias;
+    v.ids = reorder_ids;
+    const int mmax = qeft::gemv_v3_max_rows(v, m);
+    if (mmax < 1) return V3_NOT_TAKEN;
+    const int nlaunch = (m + mmax - 1) / mmax, per = (m + nlaunch - 1) / nlaunch;      // 7 rows as 4 + 3, not 6 + 1
+    if (nlaunch > max_launches) return V3_NOT_TAKEN;
+    for (int m0 = 0; m0 < m; m0 += per) {
+        v.m = m - m0 < per ? m - m0 : per;
+        v.x = (const qeft::f16*)x + (size_t)m0 * k;
+        v.y = (qeft::f16*)y + (size_t)m0 * n;
+        if (const hipError_t e = qeft::gemv_v3_launch(v, qeft::V3_MODE_PLAIN, (hipStream_t)stream)) return finish(e);
+    }
+    return QEFT_OK;
+}
+
 static int gemv_fused_impl(const void* x, const void* qweight, const void* scales, const void* scaled_zeros,
                            const void* oweight_il, const void* bias, const int* reorder_ids, const void* residual,
                            const void* sz_packed, void* y, int m, int n, int k, int group_size, int n_out,
@@ -134,37 +188,10 @@ static int gemv_fused_impl(const void* x, const void* qweight, const void* scale
     if (!x || !qweight || !scales || !scaled_zeros || !y || (n_out > 0 && !oweight_il)) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight_il))) return QEFT_ERR_ALIGN;
     if (sz_packed && !aligned16(sz_packed)) return QEFT_ERR_ALIGN;
-    if (bits == 4 && v3_route_enabled() && !residual && n % 16 == 0 && qeft::gemv_v3_ok(k, group_size, n_out) && aligned16(scales) &&
-        aligned16(scaled_zeros) && (!reorder_ids || aligned16(reorder_ids))) {
-        // The round-2 decode GEMV on the operands as the checkpoint holds them (gemv_v3.h): the scales staged raw and packed in
-        // LDS (or the sz_packed shadow when the caller has one), the outlier slab from oweight_interleaved, the o_proj gather
-        // inside the launch, m batch rows as D rows of the same MFMAs.  A batch whose x rows do not fit the block's LDS goes in
-        // several launches (as the round-1 kernel below does).
-        qeft::V3Args v{};
-        v.g.K = k;
-        v.g.n_out = n_out;
-        v.g.nsteps = k / 128;
-        v.g.nfull = (k - n_out) / 128;
-        v.g.ngroups = group_size == k ? 1 : k / 128;
-        v.g.nsets = n / 16;
-        v.qw = (const uint8_t*)qweight;
-        v.szp = (const uint8_t*)sz_packed;
-        v.scales = (const qeft::f16*)scales;
-        v.zeros = (const qeft::f16*)scaled_zeros;
-        v.ow_il = (const uint8_t*)oweight_il;
-        v.bias = (const qeft::f16*)bias;
-        v.ids = reorder_ids;
-        const int mmax = qeft::gemv_v3_max_rows(v, m);
-        if (mmax >= 1) {
-            const int nlaunch = (m + mmax - 1) / mmax, per = (m + nlaunch - 1) / nlaunch;      // 7 rows as 4 + 3, not 6 + 1
-            for (int m0 = 0; m0 < m; m0 += per) {
-                v.m = m - m0 < per ? m - m0 : per;
-                v.x = (const qeft::f16*)x + (size_t)m0 * k;
-                v.y = (qeft::f16*)y + (size_t)m0 * n;
-                if (const hipError_t e = qeft::gemv_v3_launch(v, qeft::V3_MODE_PLAIN, (hipStream_t)stream)) return finish(e);
-            }
-            return QEFT_OK;
-        }
+    if (bits == 4 && !residual) {
+        const int r = v3_rows(x, qweight, scales, scaled_zeros, nullptr, oweight_il, bias, reorder_ids, sz_packed, y, m, n, k, group_size,
+                              n_out, stream, 1 << 30);
+        if (r != V3_NOT_TAKEN) return r;
     }
     qeft::GemvArgs a;
     a.x = (const qeft::f16*)x;
@@ -227,7 +254,16 @@ static int gemm_impl(const void* x, const void* qweight, const void* scales, con
     if (int e = check_common(n, k, group_size, n_out)) return e;
     if (!x || !qweight || !scales || !scaled_zeros || !y) return QEFT_ERR_NULL;
     if (!aligned16(x) || !aligned16(qweight) || (n_out > 0 && !aligned16(oweight))) return QEFT_ERR_ALIGN;
-    if (small_m_route(m, n, workspace != nullptr && workspace_bytes > 0) && (n_out > 0) == (oweight != nullptr)) {
+    if (m <= qeft::V3_MAX_M && (n_out > 0) == (oweight != nullptr)) {
+        // up to 16 rows: the batch rows ride as A rows of the decode GEMV's MFMAs -- one weight stream (two launches at most where
+        // the caller brought the split-K workspace: a long x whose rows do not fit the LDS then falls to the split-K GEMM tier
+        // below rather than stream the weights three times; without a workspace three streams still beat an unsplit 128-row tile)
+        const int r = v3_rows(x, qweight, scales, scaled_zeros, oweight, nullptr, bias, nullptr, nullptr, y, m, n, k, group_size, n_out,
+                              stream, workspace != nullptr && workspace_bytes > 0 ? kGemmRowsOnGemvLaunches : (1 << 30));
+        if (r != V3_NOT_TAKEN) return r;
+    }
+    if (small_m_route(m, n, workspace != nullptr && workspace_bytes > 0) && (n_out > 0) == (oweight != nullptr) &&
+        !(v3_route_enabled() && n % 16 == 0 && qeft::gemv_v3_ok(k, group_size, n_out))) {
         // few rows: stream the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
         // (gemm_4bit semantics with oweight == NULL and a non-zero slice -- dead nibbles -- stays on the GEMM kernel.)
         qeft::GemvArgs a{};
@@ -321,7 +357,15 @@ int qeft_gemm_w3_dx(const void* dy, const void* qweight3, const void* scales, co
 }
 
 long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {
-    if (m < 1 || n < 1 || k < 1 || n_out < 0 || n_out >= k || small_m_route(m, n, true)) return 0;
+    if (m < 1 || n < 1 || k < 1 || n_out < 0 || n_out >= k) return 0;
+    if (m <= qeft::V3_MAX_M && k % 128 == 0 && n % 16 == 0 && (n_out == 0 || n_out == 128)) {
+        // up to 16 rows of a shape the decode GEMV serves (group size 128 assumed: the larger LDS plan): no workspace if gemm_impl
+        // will put them there, the split-K tier's otherwise (three weight streams would cost more than its partial sums)
+        const int l = v3_rows_launches(m, n, k, 128, n_out);
+        if (l >= 1 && l <= kGemmRowsOnGemvLaunches) return 0;
+    } else if (small_m_route(m, n, true)) {
+        return 0;
+    }
     int s = qeft::gemm_w4_split(m, n, k, n_out);
     const int s3 = qeft::gemm_v3_split(m, n, k, n_out);       // the loader-wave tier's split (whichever tier the launch takes, it fits)
     if (s3 > s) s = s3;

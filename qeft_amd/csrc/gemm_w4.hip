@@ -1023,7 +1023,7 @@ hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, con
             const int mb4 = (M + 127) / 128;
             // fewer than 192 tiles and a workspace: S blocks per tile, fp32 partials, the reduce launch (QEFT_GEMM_V3S=0 disables)
             static const int force_s = getenv("QEFT_GEMM_V3S") ? atoi(getenv("QEFT_GEMM_V3S")) : -1;
-            const int S3 = (force_s == 0 || force_m == 0 || !workspace || silu_gate || !ok3 || M <= 16) ? 1 : gemm_v3_split(M, N, K, outl ? n_out : 0);
+            const int S3 = (force_s == 0 || force_m == 0 || !workspace || silu_gate || !ok3) ? 1 : gemm_v3_split(M, N, K, outl ? n_out : 0);
             if (S3 > 1 && workspace_bytes >= (size_t)S3 * M * N * 4) {
                 constexpr int SMEM4 = G3_ST * 128 * BK * 2 + G3_BST * G3_B + G3_BST * G3_S;
                 auto go4 = [&](auto kern) -> hipError_t {

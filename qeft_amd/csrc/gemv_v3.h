@@ -56,14 +56,15 @@ constexpr int V3_MAX_RS = 4;    // 16-row sets per block (LDS is carved for rs_c
 constexpr int V3_MAX_SSQ = 512; // partial sums of squares a consumer accepts
 constexpr int V3_MODE_PLAIN = 0;
 constexpr int V3_MODE_PAIR = 1; // rows pair-interleaved: set g = gate rows [8g, 8g+8) then up rows [8g, 8g+8); y[8g + i] = silu(gate) * up
-constexpr int V3_MAX_M = 7;     // batch rows of one launch (the reference's gemv entries serve m = 1..7, gemv_cuda_qeft.cu:433-466)
+constexpr int V3_MAX_M = 16;    // batch rows of one launch: the A rows of one MFMA (the reference's gemv entries serve m = 1..7, gemv_cuda_qeft.cu:433-466;
+                                // 8..16 rows reach this kernel from the GEMM entries, capi.hip gemm_impl)
 // run-time flags of a launch, packed beside nblk / rs_cap in one preloaded dword (V3_KERNEL_ARGS)
 constexpr uint32_t V3_F_PERCH = 1u << 24;   // one group per row (group size == K)
 constexpr uint32_t V3_F_XN = 1u << 25;      // x is fp32 h, xn_gamma its gamma: the whole RMSNorm in this launch
 constexpr uint32_t V3_F_SZN = 1u << 26;     // scales / scaled_zeros in their CHECKPOINT layout fp16 [K/g][N] (szp = scales, xn_gamma = zeros)
 constexpr uint32_t V3_F_OWIL = 1u << 27;    // outlier slice from oweight_interleaved [N/2][256] (pack_oweight, qlinear.py:70-79)
 constexpr uint32_t V3_F_GATHER = 1u << 31;  // x[:, ids] (qlinear.py:275), ids int32 [K] in the tail
-constexpr int V3_F_M_SHIFT = 28;            // bits 28..30: m - 1
+constexpr int V3_F_M_SHIFT = 19;            // bits 19..22: m - 1 (rs_cap <= 4 sits in bits 16..18)
 
 struct V3Geom {
     int K, n_out, nsteps, nfull, ngroups, nsets;   // nsets = N / 16
@@ -108,7 +109,7 @@ struct V3Args {
     const f16* zeros;
     const uint8_t* ow_il;   // oweight_interleaved fp16 [N/2][256], used when ow == NULL and n_out > 0
     const int* ids;         // optional reorder_ids int32 [K]: the launch consumes x[:, ids]
-    int m;                  // batch rows 1..7 (0 is taken as 1); x is [m][K], y [m][N]; m > 1: PLAIN, no residual / ssq_in / xn
+    int m;                  // batch rows 1..16 (0 is taken as 1); x is [m][K], y [m][N]; m > 1: PLAIN, no residual / ssq_in / xn
     int nw;                 // waves per block chosen by the launcher (LDS sizing)
 #if defined(QEFT_LAB)
     V3Prefetch pf;          // the next launch's ring head (warm-up experiment)
@@ -164,9 +165,9 @@ __host__ __device__ constexpr int v3_szraw_bytes(int ngroups) { return (ngroups 
 // batch rows of x sit XS bytes apart: whole pieces, plus 16 bytes when there are several rows so that the A-fragment reads of
 // different batch rows (same k) fall into different banks
 __host__ __device__ constexpr int v3_x_stride(int K, int m) { return v3_x_bytes(K) + (m > 1 ? 16 : 0); }
-// per-wave partial sums: m == 1: [rs_cap][NW_MAX][16] floats; m > 1: [rs_cap][nw][8 batch rows][16]
+// per-wave partial sums: m == 1: [rs_cap][NW_MAX][16] floats; m > 1: [rs_cap][nw][8 or 16 batch rows][16]
 __host__ __device__ constexpr size_t v3_red_bytes(int rs_cap, int m = 1, int nw = V3_NW_MAX) {
-    return m > 1 ? ((size_t)rs_cap * nw * 8 * 16 * 4 + 1023) / 1024 * 1024 : ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024;
+    return m > 1 ? ((size_t)rs_cap * nw * (m > 8 ? 16 : 8) * 16 * 4 + 1023) / 1024 * 1024 : ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024;
 }
 struct V3Lds {              // byte offsets of the regions inside the block's dynamic LDS
     uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, pfl, total;
@@ -301,7 +302,7 @@ template <int N> __device__ __forceinline__ void v3_dma16_run(const void* gsrc, 
 #endif
 
 // The value a lane accumulates per row set: batch row 0 only (MB == 1: D row 0 = register 0 of the lanes kc == 0), or the four
-// D rows 4 kc .. 4 kc + 3 of the lane (MB == 2: batch rows 0..6 live in the lanes kc < 2)
+// D rows 4 kc .. 4 kc + 3 of the lane (MB == 2: batch rows 0..7 live in the lanes kc < 2, rows 8..15 in the others)
 template <int MB> struct V3Val { typedef float type; };
 template <> struct V3Val<2> { typedef f32x4 type; };
 template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_pick(const f32x4& v) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     const bool per_channel_f = FL && (nblk_rscap_flags & V3_F_PERCH) != 0, XN = FL && MB == 1 && (nblk_rscap_flags & V3_F_XN) != 0;
     const bool SZN = FL && (nblk_rscap_flags & V3_F_SZN) != 0, OWIL = FL && OUTL && (nblk_rscap_flags & V3_F_OWIL) != 0;
     const bool GATHER = FL && (nblk_rscap_flags & V3_F_GATHER) != 0;
-    const int m = MB == 1 ? 1 : (int)((nblk_rscap_flags >> V3_F_M_SHIFT) & 7u) + 1;
+    const int m = MB == 1 ? 1 : (int)((nblk_rscap_flags >> V3_F_M_SHIFT) & 15u) + 1;
     const int nblk = (int)(nblk_rscap_flags & 0xffffu);
     const int sets_q = (int)(setsq_setsr & 0xffffu), sets_r = (int)(setsq_setsr >> 16);
     // (nsets from the preloaded words: the checkpoint-layout scale pieces need N before the tail has arrived)
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     uint8_t* const owl = smem + L.owl;                                // [RSC] 4 KB: 16 plain rows (chunks ^ row) or 8 interleaved rows
     uint8_t* const epl = smem + L.epl;                                // [64 lanes][16 B]: residual | gamma_out of the block's rows
     float* const ssql = (float*)(smem + L.ssql);                      // [512] ssq_in
-    float* const red = (float*)(smem + L.red);                        // [RSC][NW][16], or [RSC][NW][8][16] (MB == 2)
+    float* const red = (float*)(smem + L.red);                        // [RSC][NW][16], or [RSC][NW][8 or 16][16] (MB == 2)
     uint8_t* const xf32 = smem + L.xf;                                // xn launches: [K] fp32 h, then its gamma [K] fp16
     uint8_t* const xg = smem + L.xg;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -801,10 +802,11 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         if (kc == 0)
             v3_static_for<0, RSC>([&](auto r) { red[(decltype(r)::value * NW + wave) * 16 + nl] = acc[r]; });
     } else {
-        if (kc < 2) {                           // batch rows 4 kc + j
+        const int RB = m > 8 ? 16 : 8;          // batch rows kept per (row set, wave)
+        if (kc < 2 || m > 8) {                  // batch rows 4 kc + j
             v3_static_for<0, RSC>([&](auto r) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) red[((size_t)(decltype(r)::value * NW + wave) * 8 + 4 * kc + j) * 16 + nl] = acc[r][j];
+                for (int j = 0; j < 4; ++j) red[((size_t)(decltype(r)::value * NW + wave) * RB + 4 * kc + j) * 16 + nl] = acc[r][j];
             });
         }
     }
@@ -814,16 +816,17 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     __syncthreads();
     V3_STAMP(5);
     if constexpr (MB == 2) {
-        // y[i][row] for the m batch rows: wave i takes batch row i (NW >= 8 > m), lane = (row set lane / 16, row lane % 16)
-        const int i = wave, rs = lane >> 4;
-        if (i < m && rs < RS) {
-            float v = 0.f;
+        // y[i][row] for the m batch rows: wave w takes batch rows w, w + NW; lane = (row set lane / 16, row lane % 16)
+        const int rs = lane >> 4, RB = m > 8 ? 16 : 8;
+        for (int i = wave; i < m; i += NW)
+            if (rs < RS) {
+                float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += red[((size_t)(rs * NW + w) * 8 + i) * 16 + nl];
-            const int row = (set0 + rs) * 16 + nl;
-            if (bias) v += (float)bias[row];
-            yout[(size_t)i * G.nsets * 16 + row] = (f16)v;
-        }
+                for (int w = 0; w < NW; ++w) v += red[((size_t)(rs * NW + w) * RB + i) * 16 + nl];
+                const int row = (set0 + rs) * 16 + nl;
+                if (bias) v += (float)bias[row];
+                yout[(size_t)i * G.nsets * 16 + row] = (f16)v;
+            }
         return;
     }
     float rs_norm = 1.f;

@@ -51,7 +51,7 @@ def test_the_enumerator_sees_an_operand_that_is_too_short(lib):
 
 # ---- the launches the reference's gemv entries make on the checkpoint-layout operands (round 3)
 @pytest.mark.parametrize("k", [256, 1024, 4096, 5120, 11008, 13824])
-@pytest.mark.parametrize("m", [1, 2, 4, 7])
+@pytest.mark.parametrize("m", [1, 2, 4, 7, 8, 9, 16])
 @pytest.mark.parametrize("gather", [0, 1])
 def test_checkpoint_layout_launches(lib, k, m, gather):
     for n in (16, 48, 640, 4096, 16 * 513, 11008, 13824):
@@ -65,5 +65,5 @@ def test_checkpoint_layout_negative_control(lib):
     for n in (16, 4096, 11008):
         assert lib.qeft_gemv_v3_check_extents_ckpt(n, 4096, 128, 128, 3, 1, 16) > 0
         assert lib.qeft_gemv_v3_check_extents_ckpt(n, 4096, 128, 0, 1, 0, 16) > 0
-    assert lib.qeft_gemv_v3_check_extents_ckpt(4096, 4096, 128, 128, 8, 0, 0) == -1       # m outside 1..7
+    assert lib.qeft_gemv_v3_check_extents_ckpt(4096, 4096, 128, 128, 17, 0, 0) == -1      # m outside 1..16
     assert lib.qeft_gemv_v3_check_extents_ckpt(4096, 4096, 64, 128, 1, 0, 0) == -1        # group size the v3 launch does not take

@@ -96,6 +96,37 @@ def test_gemv_row_shard_shapes(n, k, m):
     assert rel_err(y.cpu().numpy(), yref.astype(np.float64)) < REL_TOL
 
 
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008), (5120, 5120), (13824, 5120)])
+@pytest.mark.parametrize("m", [8, 11, 16])
+def test_gemm_entry_8_to_16_rows_on_the_decode_gemv(n, k, m):
+    """QuantLinear.forward sends 8 and more rows to gemm_4bit (+ F.linear on the outlier slice, qlinear.py:251-266).  Up to 16
+    rows ride as A rows of the decode GEMV's MFMAs (one weight stream; the plain oweight rows, checkpoint-layout scales): every
+    output vs the oracle, element-wise, and the variant the routing must take -- a long x whose 16 rows do not fit the LDS in
+    two launches goes to the split-K GEMM tier instead."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, R, G, seed=n + k + m, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, R, seed=m)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"], t["bias"])
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    two_launches_hold = k <= 5120 or m <= 12
+    assert (variant == "gemv_v3_mb") == two_launches_hold, (variant, n, k, m)
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], bufs["bias"], G).astype(np.float64)
+    got = y.cpu().numpy()
+    assert got.shape == (m, n)
+    assert rel_err(got, yref) < REL_TOL
+    assert elem_err_ok(got, yref), (variant, n, k, m)
+    # no outlier slice: gemm_4bit's own semantics (N from the qweight rows)
+    if n == 4096 and k == 4096:
+        b0 = O.make_layer(n, k, 0, G, seed=5)
+        t0 = layer_to_torch(b0, DEV)
+        y0 = qeft_cuda.gemm_4bit(torch.from_numpy(x).to(DEV), t0["qweight"], t0["scales"], t0["scaled_zeros"])
+        assert _lib.last_variant() == "gemv_v3_mb"
+        ref0 = O.quant_linear(x, b0["qweight"], b0["scales"], b0["scaled_zeros"], None, None, G).astype(np.float64)
+        assert elem_err_ok(y0.cpu().numpy(), ref0)
+
+
 def test_variant_names_follow_the_routing():
     """The routing tiers below the BASELINE sizes keep their own names (and their own tests in test_gpu_gemm.py)."""
     from qeft_amd import _lib, qeft_cuda
@@ -108,7 +139,7 @@ def test_variant_names_follow_the_routing():
         qeft_cuda.gemm_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
         seen[m] = _lib.last_variant()
     torch.cuda.synchronize()
-    assert seen[8] == "gemv_smallm", seen
+    assert seen[8] == "gemv_v3_mb", seen                         # up to 16 rows: A rows of the decode GEMV's MFMAs
     assert seen[200] == "gemm_v3_128x128+splitk", seen           # 8 tiles: two blocks per tile through the split-K workspace
     dy = torch.zeros(64, n, dtype=torch.float16, device=DEV)
     qeft_cuda.gemm_4bit_dx(dy, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"])
