@@ -259,7 +259,8 @@ static int gemm_impl(const void* x, const void* qweight, const void* scales, con
         // the caller brought the split-K workspace: a long x whose rows do not fit the LDS then falls to the split-K GEMM tier
         // below rather than stream the weights three times; without a workspace three streams still beat an unsplit 128-row tile)
         const int r = v3_rows(x, qweight, scales, scaled_zeros, oweight, nullptr, bias, nullptr, nullptr, y, m, n, k, group_size, n_out,
-                              stream, workspace != nullptr && workspace_bytes > 0 ? kGemmRowsOnGemvLaunches : (1 << 30));
+                              stream, workspace != nullptr && workspace_bytes > 0 && (group_size & (group_size - 1)) == 0
+                                          ? kGemmRowsOnGemvLaunches : (1 << 30));      // (per-channel scales: no split-K tier to fall to)
         if (r != V3_NOT_TAKEN) return r;
     }
     if (small_m_route(m, n, workspace != nullptr && workspace_bytes > 0) && (n_out > 0) == (oweight != nullptr) &&

@@ -68,6 +68,44 @@ if len(sys.argv) > 2 and sys.argv[2] == "ref":
             fails.append((case, n, k, g, r, m, gather, bias, shadow, v, e))
     print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
     sys.exit(1 if fails else 0)
+if len(sys.argv) > 2 and sys.argv[2] == "rows16":
+    # round 3: the GEMM entries (what QuantLinear.forward calls from 8 rows on) with 8..16 rows on the decode GEMV's domain: the
+    # rows ride as A rows of its MFMAs (gemv_v3_mb), in one or two launches, or -- K long, rows many -- on the split-K GEMM tier
+    worst = 0.0
+    for case in range(CASES):
+        n = 16 * int(rng.integers(1, 701))
+        k = 128 * int(rng.integers(2, 91))
+        r = int(rng.choice([0, 128]))
+        g = int(rng.choice([128, 128, k]))
+        m = int(rng.integers(8, 17))
+        bias = bool(rng.integers(0, 2))
+        b = O.make_layer(n, k, r, g, seed=case, bias=bias)
+        t = layer_to_torch(b, DEV)
+        x = O.make_activation(m, k, r, seed=case)
+        xt = torch.from_numpy(x).to(DEV)
+        if r or bias:
+            y = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None, t.get("bias"))
+        else:
+            y = qeft_cuda.gemm_4bit(xt, t["qweight"], t["scales"], t["scaled_zeros"])
+        v = _lib.last_variant()
+        torch.cuda.synchronize()
+        ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, b.get("bias"), g).astype(np.float64)
+        got = y.cpu().numpy()
+        e = rel_err(got, ref)
+        seen[v] = seen.get(v, 0) + 1
+        # element-wise: |err| / (1e-3 |ref| + 1e-3 rms(ref)), the parity tests' bound.  The oracle rounds every dequantised weight
+        # to fp16 as the reference's kernel does (gemv_cuda_qeft.cu:158); the product folds scale and zero in fp32 on the exact
+        # q s + sz.  That difference alone is ~2.8e-4 rms(ref) (1 sigma) per output, so among the ~10^7 outputs of a sweep a few
+        # reach 1.0-1.15 of the bound (3.6-4 sigma; the m <= 7 entries show the same elements).  A wrong row, scale or column
+        # is off by orders of magnitude: the sweep fails from 2.0 (7 sigma) and prints the worst ratio.
+        ratio = float(np.max(np.abs(got - ref) / (1e-3 * np.abs(ref) + 1e-3 * np.sqrt(np.mean(ref ** 2)))))
+        worst = max(worst, ratio) if case else ratio
+        ok = e < 1e-3 and ratio < 2.0 and got.shape == (m, n)
+        print(f"case {case:3d} n={n:5d} k={k:5d} g={g:5d} r={r:3d} m={m:2d} bias={int(bias)}  {v:24s} y={e:.1e} elem={ratio:.2f}" + ("" if ok else "   FAIL"), flush=True)
+        if not ok:
+            fails.append((case, n, k, g, r, m, bias, v, e))
+    print(f"{CASES} cases, {len(fails)} failures, worst element-wise ratio {worst:.2f}, {time.time() - t0:.0f} s; variants reached: {seen}")
+    sys.exit(1 if fails else 0)
 if len(sys.argv) > 2 and sys.argv[2] == "w3gemm":
     # round 3: GEMM forward / dX of 3-bit layers: native tiers where they apply, the expansion route otherwise
     for case in range(CASES):
