@@ -94,6 +94,13 @@ static bool v3_route_enabled() {
     return on != 0;
 }
 
+// QEFT_GEMV_XG=0: batch rows whose x does not fit the LDS go as several launches / to the split-K GEMM tier (A/B timing)
+static int xg_route_mode() {      // 0: never, 1: where the x rows do not fit the LDS, 2 (lab): every batch-row launch without a gather
+    static const int on = [] { const char* e = getenv("QEFT_GEMV_XG"); return e ? atoi(e) : 1; }();
+    return on;
+}
+static bool xg_route_enabled() { return xg_route_mode() != 0; }
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int check_common(int n, int k, int g, int n_out) {
@@ -141,7 +148,11 @@ static int v3_rows_launches(int m, int n, int k, int group_size, int n_out) {
     v.g.nfull = (k - n_out) / 128;
     v.g.ngroups = group_size == k ? 1 : k / 128;
     v.g.nsets = n / 16;
-    const int mmax = qeft::gemv_v3_max_rows(v, m);
+    int mmax = qeft::gemv_v3_max_rows(v, m);
+    if (mmax < m && m > 1 && xg_route_enabled()) {
+        v.xg = true;
+        if (qeft::gemv_v3_max_rows(v, m) >= m) mmax = m;
+    }
     return mmax < 1 ? 0 : (m + mmax - 1) / mmax;
 }
 constexpr int kGemmRowsOnGemvLaunches = 2;      // the GEMM entries put up to 16 rows on the decode GEMV if that takes two launches at most
@@ -166,7 +177,13 @@ static int v3_rows(const void* x, const void* qweight, const void* scales, const
     v.ow_il = (const uint8_t*)oweight_il;
     v.bias = (const qeft::f16*)bias;
     v.ids = reorder_ids;
-    const int mmax = qeft::gemv_v3_max_rows(v, m);
+    int mmax = qeft::gemv_v3_max_rows(v, m);
+    if ((mmax < m || xg_route_mode() == 2) && m > 1 && !reorder_ids && xg_route_enabled()) {
+        // the x rows do not fit the block's LDS: the lanes read their fragments from global memory instead (one launch, any K)
+        v.xg = true;
+        const int mx = qeft::gemv_v3_max_rows(v, m);
+        if (mx >= m) mmax = mx; else v.xg = false;
+    }
     if (mmax < 1) return V3_NOT_TAKEN;
     const int nlaunch = (m + mmax - 1) / mmax, per = (m + nlaunch - 1) / nlaunch;      // 7 rows as 4 + 3, not 6 + 1
     if (nlaunch > max_launches) return V3_NOT_TAKEN;

@@ -111,6 +111,7 @@ struct V3Args {
     const int* ids;         // optional reorder_ids int32 [K]: the launch consumes x[:, ids]
     int m;                  // batch rows 1..16 (0 is taken as 1); x is [m][K], y [m][N]; m > 1: PLAIN, no residual / ssq_in / xn
     int nw;                 // waves per block chosen by the launcher (LDS sizing)
+    bool xg;                // m > 1: the lanes read their x fragments from global memory (no x rows in LDS): any K with 16 rows
 #if defined(QEFT_LAB)
     V3Prefetch pf;          // the next launch's ring head (warm-up experiment)
 #endif
@@ -172,10 +173,10 @@ __host__ __device__ constexpr size_t v3_red_bytes(int rs_cap, int m = 1, int nw 
 struct V3Lds {              // byte offsets of the regions inside the block's dynamic LDS
     uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, pfl, total;
 };
-__host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_cap, int m, int nw, bool xn, bool szn, bool gather) {
+__host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_cap, int m, int nw, bool xn, bool szn, bool gather, bool xg = false) {
     V3Lds L;
     uint32_t o = 0;
-    L.xs = o;   o += ((uint32_t)m * v3_x_stride(K, m) + 1023u) / 1024u * 1024u;          // [m][K] fp16 as the MFMAs read it
+    L.xs = o;   o += xg ? 0u : ((uint32_t)m * v3_x_stride(K, m) + 1023u) / 1024u * 1024u;   // [m][K] fp16 as the MFMAs read it (xg: x stays in global memory)
     L.szl = o;  o += (uint32_t)rs_cap * v3_sz_bytes(ngroups);                               // [rs_cap][groups][16] u32
     L.owl = o;  o += n_out > 0 ? (uint32_t)rs_cap * 4096u : 0u;                             // [rs_cap] 4 KB outlier slab (swizzled)
     L.epl = o;  o += 1024;                                                                  // epilogue operands
@@ -338,7 +339,7 @@ __host__ __device__ constexpr int v3_unroll_steps(int D, int RSC) {
 //      stream their last set twice and drop the copy's results.
 // FL: the run-time flags (V3_F_*: per-channel scales, consumer-side norm, checkpoint-layout operands, gather) are honoured; false
 //     for the plain launches of the decode engine, which then carry no trace of those paths.
-template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1, bool FL = true>
+template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1, bool FL = true, bool XG = false>
 __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     static_assert(MB == 1 || (MODE == V3_MODE_PLAIN && BITS == 4), "several batch rows: plain 4-bit launches only");
     static_assert(RSC >= 1 && RSC <= V3_MAX_RS && D >= 2, "row sets per block 1..4, at least two loads in flight per wave");
     static_assert(FL || MB == 1, "the batch-row launches always come with flags");
+    static_assert(!XG || (MB == 2 && D >= 4), "x fragments from global memory: batch-row launches with a deep ring");
     typedef typename V3Val<MB>::type val_t;
     // the leading parameters arrive in SGPRs (kernarg preload); the tail is one batch of scalar loads issued here and waited
     // for once, behind the ring issue (the pin below) -- argument loads that hipcc leaves next to their first use each cost a
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                  "s"(szp), "s"(ow), "s"(xn_gamma));
 
     extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];
-    const V3Lds L = v3_lds(G.K, G.ngroups, OUTL ? 128 : 0, RSC, m, NW, XN, SZN, GATHER);
+    const V3Lds L = v3_lds(G.K, G.ngroups, OUTL ? 128 : 0, RSC, m, NW, XN, SZN, GATHER, XG);
     const int XB = v3_x_bytes(G.K), SZB = v3_sz_bytes(G.ngroups), XS = v3_x_stride(G.K, m);
     uint8_t* const xs = smem + L.xs;                                  // [m][K] fp16 raw (rows XS apart)
     uint8_t* const szl = smem + L.szl;                                // [RSC][SZB / 64][16] u32
@@ -461,6 +463,8 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     auto stage_all = [&]() {
         if (ABL & 16) {
             // lab: no staging at all (the results are garbage) -- what the whole staging prologue costs
+        } else if (XG) {
+            // x fragments come straight from global memory (step 4)
         } else if (!XN) {
             // (a gathering launch stages the rows as they are into xraw; step 3b writes xs)
             const uint32_t xdst = lds0 + (GATHER ? L.xraw : L.xs), xstr = GATHER ? (uint32_t)XB : (uint32_t)XS;
@@ -611,7 +615,8 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     asm volatile("" : "+v"(MAGIC), "+v"(NEG1024));
     const v3h8 c8 = __builtin_bit_cast(v3h8, u32x4{NEG1024, NEG1024, NEG1024, NEG1024});
     // this lane's 32-k chunk of a step: four 16-byte slots; A row = lane & 15 = batch row (rows >= m re-read row m - 1)
-    const uint8_t* xa = xs + kc * 64 + (MB == 1 ? 0 : (size_t)min(nl, m - 1) * XS);
+    // (XG: the same 64 bytes per lane and step from the x rows in global memory -- L2 hits, every block reads all of x either way)
+    const uint8_t* xa = XG ? xptr + (size_t)min(nl, m - 1) * G.K * 2 + kc * 64 : xs + kc * 64 + (MB == 1 ? 0 : (size_t)min(nl, m - 1) * XS);
     const bool per_channel = G.ngroups == 1;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -652,7 +657,10 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     }
 
     if (nsw > 0) {
-        v3h8 xA[4], xB[4];                 // x fragments of two consecutive steps (the roles alternate step by step)
+        // x fragments of consecutive steps (the roles rotate step by step): two sets from LDS; XG: four, loaded from global memory
+        // three steps ahead (an L2 round trip under load is ~1 us, a step a few hundred ns)
+        constexpr int XP = XG ? 4 : 2, XD = XP - 1;
+        v3h8 xr[XP][4];
         val_t alo = v3_zero<MB>(), ahi = v3_zero<MB>();        // -1024 S_lo, -1024 S_hi of the current step
         val_t nlo = v3_zero<MB>(), nhi = v3_zero<MB>();        // the next step's sums, computed one step ahead
         // LDS addresses of the wave's current step: x fragments (256 B per step) and the set-0 scale words (64 B per step / group)
@@ -678,9 +686,19 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                 hi = v3_pick<MB>(A1);
             }
         };
-        load_x(xA, xp);
+        // XG: address of the fragments of the step XD ahead, clamped to the wave's last step
+        const uint8_t* const xlast = xp + (size_t)(nsw - 1) * (NW * 256);
+        const uint8_t* xq = xp;
+        load_x(xr[0], xp);
+        if constexpr (XG) {
+            v3_static_for<1, XD>([&](auto d) {
+                xq = xq + NW * 256 <= xlast ? xq + NW * 256 : xlast;
+                load_x(xr[decltype(d)::value], xq);
+            });
+            xq = xq + NW * 256 <= xlast ? xq + NW * 256 : xlast;
+        }
         uint32_t szw = *(const uint32_t*)sp;                   // scale word of the next consume
-        bias_sums(xA, alo, ahi);
+        bias_sums(xr[0], alo, ahi);
         // Software pipeline: the products of a (step, row set) are folded into the accumulators one consume LATER, behind
         // the MFMAs of the next one -- nothing reads an MFMA result right behind the MFMA (that wait was ~10 % of a launch).
         val_t pv_lo = v3_zero<MB>(), pv_hi = v3_zero<MB>(), pv_alo = v3_zero<MB>(), pv_ahi = v3_zero<MB>();
@@ -691,10 +709,14 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         };
         // one (step, row set): xc = the step's fragments, xnx = the next step's (fetched at the step's first row set, their bias
         // sums formed behind its last); prev_rs = the row set of the previous consume (whose products are folded here)
-        auto consume = [&](ring_t& slot, v3h8 (&xc)[4], v3h8 (&xnx)[4], auto rs_tag, bool more_steps) {
+        auto consume = [&](ring_t& slot, v3h8 (&xc)[4], v3h8 (&xnx)[4], v3h8 (&xld)[4], auto rs_tag, bool more_steps) {
             constexpr int rs = decltype(rs_tag)::value;
             constexpr int prev_rs = (rs + RSC - 1) % RSC;
-            if (rs == 0) load_x(xnx, xp + (more_steps ? NW * 256 : 0));          // the next step's fragments: in flight during this step
+            if constexpr (XG) {
+                if (rs == 0) load_x(xld, xq);                                    // the fragments of the step XD ahead (xld: the previous step's set)
+            } else {
+                if (rs == 0) load_x(xnx, xp + (more_steps ? NW * 256 : 0));      // the next step's fragments: in flight during this step
+            }
             // the next consume's scale word: the next row set of this step, or set 0 of the next step
             const uint32_t szw_n = rs + 1 < RSC ? *(const uint32_t*)(sp + (size_t)(rs + 1) * SZB)
                                                 : *(const uint32_t*)(sp + (more_steps ? s_stride : 0u));
@@ -754,11 +776,13 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                 alo = nlo;
                 ahi = nhi;
                 if (more_steps) { xp += NW * 256; sp += s_stride; }
+                if constexpr (XG) xq = xq + NW * 256 <= xlast ? xq + NW * 256 : xlast;
             }
         };
         // The unrolled round: US steps = US * RSC consumes = a whole number of ring turns, an even number of steps.
-        constexpr int US = v3_unroll_steps(D, RSC);
-        static_assert((US * RSC) % D == 0 && US % 2 == 0, "a round must return every ring slot and both fragment sets to their roles");
+        constexpr int US0 = v3_unroll_steps(D, RSC);
+        constexpr int US = XG ? US0 * XP / v3_gcd(US0, XP) : US0;
+        static_assert((US * RSC) % D == 0 && US % XP == 0, "a round must return every ring slot and every fragment set to its role");
         int i = 0;                                              // step counter of the wave
         auto round = [&](bool guarded) {
             v3_static_for<0, US>([&](auto u_tag) {
@@ -768,8 +792,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                     v3_static_for<0, RSC>([&](auto rs_tag) {
                         constexpr int rs = decltype(rs_tag)::value;
                         constexpr int c = u * RSC + rs;
-                        if constexpr (u % 2 == 0) consume(ring[c % D], xA, xB, rs_tag, more);
-                        else consume(ring[c % D], xB, xA, rs_tag, more);
+                        consume(ring[c % D], xr[u % XP], xr[(u + 1) % XP], xr[(u + XD) % XP], rs_tag, more);
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 }

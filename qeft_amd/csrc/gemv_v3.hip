@@ -57,7 +57,7 @@ static bool gemv_v3_plan(V3Args& a, int& nw, size_t& smem) {
     nw = f_nw == 4 || f_nw == 8 ? f_nw : (nblk > 256 && a.m <= 1 ? 4 : V3_NW);
     if (a.m > 1) nw = V3_NW;
     a.nw = nw;
-    smem = v3_lds(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.m, nw, a.xn_gamma != nullptr && a.szp != nullptr, a.szp == nullptr, a.ids != nullptr).total;
+    smem = v3_lds(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.m, nw, a.xn_gamma != nullptr && a.szp != nullptr, a.szp == nullptr, a.ids != nullptr, a.xg).total;
     return smem <= 160 * 1024 && nblk < 65536;       // (nblk, sets_r share dwords with rs_cap, sets_q)
 }
 
@@ -77,6 +77,7 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     size_t smem;
     if (a.m > V3_MAX_M || !gemv_v3_plan(a, nw, smem)) return hipErrorInvalidValue;
     if (a.m > 1 && (mode != V3_MODE_PLAIN || a.bits == 3 || a.residual || a.ssq_in || a.xn_gamma)) return hipErrorInvalidValue;
+    if (a.xg && (a.m <= 1 || a.ids)) return hipErrorInvalidValue;      // x from global memory: batch-row launches without a gather
     if (!a.szp && (a.xn_gamma || !a.scales || !a.zeros)) return hipErrorInvalidValue;     // (the zeros pointer uses xn_gamma's slot)
     static const int f_d = env_int("QEFT_GEMV_DEPTH");     // lab override: 2, or 4 (= the deep form of the block's RSC: 4 or 6 loads)
     // Ring depth (tools/gemv_v3_lab.hip, interleaved timing, profiles/r03_gemv_lab.txt): where a CU holds ONE block and a wave has
@@ -84,9 +85,9 @@ hipError_t gemv_v3_launch(V3Args a, int mode, hipStream_t st) {
     // q|k|v 7.06 (6) / 7.44 (4) / 7.69 us (2), down_proj 7.18 (4) / 7.59 (2) (the batch-row launches likewise: 8.65 vs 8.81); short launches (o_proj: 4 loads per wave) and
     // two blocks per CU (gate|up) keep 2: 4.58 vs 4.78, 10.97 vs 11.07 / 11.50.
     const int loads_per_wave = ceil_div(a.g.nfull, nw) * a.rs_cap;
-    const int depth = f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 ? 4 : 2);
+    const int depth = a.xg ? 4 : f_d == 2 || f_d == 4 ? f_d : (a.nblk <= 256 && loads_per_wave >= 8 ? 4 : 2);     // (xg: the deep-ring instantiations only)
     const bool w3 = a.bits == 3;
-    g_last_variant = a.m > 1 ? "gemv_v3_mb" : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
+    g_last_variant = a.m > 1 ? (a.xg ? "gemv_v3_mb_xg" : "gemv_v3_mb") : mode == V3_MODE_PAIR ? (w3 ? "gemv_v3_w3_pair" : "gemv_v3_pair") : (w3 ? "gemv_v3_w3" : "gemv_v3");
     // plain launches (no run-time flag, one batch row): the instantiations without the flag paths (gemv_v3_plain.hip)
     if (a.m <= 1 && (v3_flags(a) & (V3_F_PERCH | V3_F_XN | V3_F_SZN | V3_F_OWIL | V3_F_GATHER)) == 0)
         return gemv_v3_dispatch_plain(a, mode, smem, depth, st);
@@ -154,6 +155,13 @@ long long gemv_v3_count_out_of_range_ckpt(const V3Geom& G, int n_rows_have, int 
     const int nblk = gemv_v3_blocks(G.nsets), rs_cap = ceil_div(G.nsets, nblk);
     const int XB = v3_x_bytes(G.K), SRB = v3_szraw_bytes(G.ngroups), XS = v3_x_stride(G.K, m);
     // (the strided scale rows assume the operand really has G.nsets * 16 columns: a shrunk operand is the negative control)
+    // x fragments read by the lanes from global memory (xg launches: m > 1, no gather): lane (batch row nl clamped to m - 1, chunk kc)
+    // reads 64 bytes of every 128-k step, the outlier step included
+    if (!gather && m > 1)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int nl = lane & 15, kc = lane >> 4, row = nl < m - 1 ? nl : m - 1;
+            for (int step = 0; step < G.nsteps; ++step) bad += (size_t)row * G.K * 2 + (size_t)step * 256 + kc * 64 + 64 > x_bytes;
+        }
     for (int nw = 4; nw <= 16; nw *= 2) {
         const V3Lds L = v3_lds(G.K, G.ngroups, G.n_out, rs_cap, m, nw, false, true, gather);
         if (L.total > 160 * 1024) continue;     // not launched (gemv_v3_plan)

@@ -19,7 +19,11 @@ static hipError_t launch_dmr(const V3Args& a, int mode, int nblk, size_t smem, h
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, st, V3_KERNEL_ARGS(a));
         return hipGetLastError();
     };
-    if constexpr (NW == 8 && BITS == 4 && FL) {       // several batch rows (the reference's gemv entries, m = 2..7): plain launches
+    if constexpr (NW == 8 && BITS == 4 && FL) {       // several batch rows (the reference's gemv entries, m = 2..7; 8..16 from the GEMM entries): plain launches
+        if constexpr (D >= 4) {
+            if (a.m > 1 && a.xg) return go(gemv_v3_kernel<8, D, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC, true, true>);     // x read from global memory
+        }
+        if (a.m > 1 && a.xg) return hipErrorInvalidValue;
         if (a.m > 1) return go(gemv_v3_kernel<8, D, OUTL, V3_MODE_PLAIN, 0, 4, 2, RSC, true>);
     }
     if (a.m > 1) return hipErrorInvalidValue;

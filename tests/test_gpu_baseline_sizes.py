@@ -101,8 +101,8 @@ def test_gemv_row_shard_shapes(n, k, m):
 def test_gemm_entry_8_to_16_rows_on_the_decode_gemv(n, k, m):
     """QuantLinear.forward sends 8 and more rows to gemm_4bit (+ F.linear on the outlier slice, qlinear.py:251-266).  Up to 16
     rows ride as A rows of the decode GEMV's MFMAs (one weight stream; the plain oweight rows, checkpoint-layout scales): every
-    output vs the oracle, element-wise, and the variant the routing must take -- a long x whose 16 rows do not fit the LDS in
-    two launches goes to the split-K GEMM tier instead."""
+    output vs the oracle, element-wise, and the variant the routing must take -- x rows staged in LDS where they fit, read by the
+    lanes from global memory (gemv_v3_mb_xg) where they do not."""
     from qeft_amd import _lib, qeft_cuda
     bufs = O.make_layer(n, k, R, G, seed=n + k + m, bias=True)
     t = layer_to_torch(bufs, DEV)
@@ -110,8 +110,9 @@ def test_gemm_entry_8_to_16_rows_on_the_decode_gemv(n, k, m):
     y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"], t["bias"])
     variant = _lib.last_variant()
     torch.cuda.synchronize()
-    two_launches_hold = k <= 5120 or m <= 12
-    assert (variant == "gemv_v3_mb") == two_launches_hold, (variant, n, k, m)
+    # (x rows that fit the block's LDS are staged there -- two launches for the widest blocks; longer ones are read from global memory)
+    xg = k > 5120 or (k == 5120 and (m == 16 or (n == 13824 and m >= 11))) or (n == 11008 and m == 16)      # (the LDS plan of v3_lds)
+    assert variant == ("gemv_v3_mb_xg" if xg else "gemv_v3_mb"), (variant, n, k, m)
     yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], bufs["bias"], G).astype(np.float64)
     got = y.cpu().numpy()
     assert got.shape == (m, n)

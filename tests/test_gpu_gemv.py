@@ -51,8 +51,9 @@ def run_case(n, k, r, g, m, seed, bias=False, gather=False, residual=False, fuse
     assert rel_err(y, yref) < REL_TOL, (rel_err(y, yref), n, k, r, g, m, variant)
     assert elem_err_ok(y, yref), (n, k, r, g, m, variant)
     if v3_takes(n, k, r, g, residual):
-        # (a batch whose x rows do not fit the block's LDS is split into several launches; the last one names the variant)
-        assert variant in ("gemv_v3", "gemv_v3_mb") and (m > 1 or variant == "gemv_v3"), (variant, n, k, r, g, m)
+        # (a batch whose x rows do not fit the block's LDS reads x from global memory -- _xg -- or, with a gather, goes as several
+        #  launches; the last one names the variant)
+        assert variant in ("gemv_v3", "gemv_v3_mb", "gemv_v3_mb_xg") and (m > 1 or variant == "gemv_v3"), (variant, n, k, r, g, m)
     else:
         assert variant in ("gemv_mfma", "gemv_valu"), (variant, n, k, r, g, m)
     return y
@@ -102,9 +103,10 @@ def test_reference_entry_batches_1_to_7_on_llama_shapes(n, k):
         variant = _lib.last_variant()
         torch.cuda.synchronize()
         yref = x.astype(np.float64) @ w.astype(np.float64).T
-        # (K = 11008 / 13824: seven rows of x exceed the block's LDS and go as 4 + 3 or 3 + 3 + 1 rows: the last launch names the variant)
-        assert variant == "gemv_v3" if m == 1 else variant in ("gemv_v3_mb", "gemv_v3"), (variant, m)
-        assert variant == "gemv_v3_mb" or m == 1 or k > 8192, (variant, m)
+        # (K = 11008 / 13824: seven rows of x exceed the block's LDS: the lanes read their x fragments from global memory, _xg)
+        assert variant == "gemv_v3" if m == 1 else variant in ("gemv_v3_mb", "gemv_v3_mb_xg"), (variant, m, k)
+        assert variant != "gemv_v3_mb_xg" or k > 8192, (variant, m, k)             # short rows always fit
+        assert variant == "gemv_v3_mb_xg" or m * k * 2 <= 160 * 1024, (variant, m, k)
         assert rel_err(y.cpu().numpy(), yref) < REL_TOL, (m, rel_err(y.cpu().numpy(), yref))
         assert elem_err_ok(y.cpu().numpy(), yref), m
 
