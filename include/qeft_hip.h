@@ -202,6 +202,12 @@ int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const voi
 int qeft_single_query_attention(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
                                 int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
                                 int n_kv_heads, int max_seq, qeft_stream_t stream);
+/* qeft_single_query_attention_alibi: the same with the reference's alibi_slopes_ (fp32 [n_heads], ft_attention.cpp:149-154): the
+ * head's linear position bias slope * (key position - query position) is added to the scaled score
+ * (decoder_masked_multihead_attention_template.hpp:1335-1345). */
+int qeft_single_query_attention_alibi(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                                      int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
+                                      int n_kv_heads, int max_seq, const float* alibi_slopes, qeft_stream_t stream);
 
 /* ---- v3 decode linear (batch 1): the decode engine's production GEMV (csrc/gemv_v3.h) ------------------------------
  *     y[n] = Wdeq . x (+ bias)                                          (gemv_4bit_qeft, gemv_cuda_qeft.cu:392-513, m = 1)

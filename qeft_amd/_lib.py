@@ -67,6 +67,7 @@ SIGNATURES = {
     "qeft_rope_rows": [_p, _p, _p, _i, _i, _i, _p],
     "qeft_residual_norm": [_p, _p, _p, _p, _p, _p, _i, _p],
     "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    "qeft_single_query_attention_alibi": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
 }
 

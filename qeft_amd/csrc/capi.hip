@@ -39,7 +39,8 @@ hipError_t rmsnorm_launch(const void* x, const void* add, const void* gamma, voi
 hipError_t silu_mul_launch(const void* gate, const void* up, void* out, int n, hipStream_t st);
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
                                    void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
-                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout = false);
+                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout = false,
+                                   const float* alibi_slopes = nullptr);
 size_t attn_workspace_bytes(int n_heads, int S);
 hipError_t token_begin_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
                               void* rope_row, int hidden, int vocab, int max_seq, hipStream_t st);
@@ -642,16 +643,29 @@ int qeft_rope_attn_decode(const void* q, const void* k, const void* v, const voi
                                                 n_heads, n_kv_heads, max_seq, n_split, tab_rows, (hipStream_t)stream));
 }
 
-int qeft_single_query_attention(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
-                                int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
-                                int n_kv_heads, int max_seq, qeft_stream_t stream) {
+static int sqa_impl(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab, int tab_rows, void* k_cache_ft,
+                    void* v_cache, const int* pos, void* out, int n_heads, int n_kv_heads, int max_seq, const float* alibi_slopes,
+                    qeft_stream_t stream) {
     if (tab_rows != 1 && tab_rows < max_seq) return QEFT_ERR_SHAPE;
     if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || max_seq < 16 || max_seq % 16 != 0 || max_seq > 32768)
         return QEFT_ERR_SHAPE;
     if (!q || !k || !v || !cos_tab || !sin_tab || !k_cache_ft || !v_cache || !pos || !out) return QEFT_ERR_NULL;
     if (!aligned16(k_cache_ft) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
     return finish(qeft::rope_attn_decode_launch(q, k, v, cos_tab, sin_tab, k_cache_ft, v_cache, pos, nullptr, out, nullptr,
-                                                n_heads, n_kv_heads, max_seq, 1, tab_rows, (hipStream_t)stream, true));
+                                                n_heads, n_kv_heads, max_seq, 1, tab_rows, (hipStream_t)stream, true, alibi_slopes));
+}
+
+int qeft_single_query_attention(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                                int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
+                                int n_kv_heads, int max_seq, qeft_stream_t stream) {
+    return sqa_impl(q, k, v, cos_tab, sin_tab, tab_rows, k_cache_ft, v_cache, pos, out, n_heads, n_kv_heads, max_seq, nullptr, stream);
+}
+
+int qeft_single_query_attention_alibi(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,
+                                      int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
+                                      int n_kv_heads, int max_seq, const float* alibi_slopes, qeft_stream_t stream) {
+    if (!alibi_slopes) return QEFT_ERR_NULL;
+    return sqa_impl(q, k, v, cos_tab, sin_tab, tab_rows, k_cache_ft, v_cache, pos, out, n_heads, n_kv_heads, max_seq, alibi_slopes, stream);
 }
 
 // ---- v3 decode linear (gemv_v3.h): fills the geometry, validates, launches

@@ -131,13 +131,14 @@ __device__ __forceinline__ size_t kcache_off(int p, int chunk, int max_seq) {
 // Parameter order: what the first loads need comes first -- the leading 13 dwords of the kernel-argument segment are
 // preloaded into SGPRs at wave launch (build flag -amdgpu-kernarg-preload-count), the rest arrives by scalar loads that
 // overlap those first vector loads.  DBG (lab only, tools/attn_timeline.py): per-wave phase stamps.
-template <int PRE, int DH = 1, bool KFT = false, bool DBG = false>
+template <int PRE, int DH = 1, bool KFT = false, bool DBG = false, bool ALIBI = false>
 __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const int* __restrict__ pos_ptr, const int* __restrict__ out_pos,
                                                                const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ v, const float* __restrict__ cs,
                                                                uint32_t heads_kv_s_tab, const float* __restrict__ sn,
                                                                f16* __restrict__ kc, f16* __restrict__ vc, f16* __restrict__ out,
-                                                               float* __restrict__ ws, int max_seq, unsigned long long* dbg_ptr) {
+                                                               float* __restrict__ ws, int max_seq, unsigned long long* dbg_ptr,
+                                                               const float* __restrict__ alibi) {
     constexpr int HD = 128;
     const int n_heads = (int)(heads_kv_s_tab & 0xfffu), n_kv = (int)((heads_kv_s_tab >> 12) & 0xfffu);
     const int S = (int)((heads_kv_s_tab >> 24) & 0xfu), tab_rows = (int)(heads_kv_s_tab >> 28);     // 1: cs / sn are this position's row; 0: the whole table
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const int* __rest
     f16* kch = kc + (size_t)hk * max_seq * HD;
     f16* vch = vc + (size_t)hk * max_seq * HD;
     const bool appender = (sp == 0) && (dhi == 0) && (h % grp == 0);
+    // ALIBI (the reference's single_query_attention boundary only): the head's linear position bias, slope * (key - query position)
+    // added to the scaled score (decoder_masked_multihead_attention_template.hpp:1335-1345, no padding tokens)
+    const float slope = ALIBI ? alibi[h] : 0.f;
 
     // ---- loads that do not depend on pos.  All of them are unconditional (addresses selected, never branched on)
     // and nothing is converted here: a conversion or a divergent branch makes the compiler wait for the load on the
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(256) void rope_attn_decode_kernel(const int* __rest
         }
         sdot += dpp_mov<0xB1>(sdot);
         sdot += dpp_mov<0x4E>(sdot);
+        if constexpr (ALIBI) sdot += slope * (float)(p - pos);
         if (p >= L) sdot = -3.0e38f;         // fetched but outside the context (possibly uninitialised cache rows)
         if (qd == 0) prob[p] = sdot;
         lmax = fmaxf(lmax, sdot);
@@ -680,7 +685,8 @@ size_t attn_workspace_bytes(int n_heads, int S) { return S > 1 ? ((size_t)n_head
 
 hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, const void* cs, const void* sn, void* kc,
                                    void* vc, const int* pos, const int* out_pos, void* out, void* ws, int n_heads,
-                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout) {
+                                   int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout,
+                                   const float* alibi_slopes) {
     const size_t smem = (size_t)(max_seq + 16) * 4 + 16 * 128 * 4 + 64 * 4 + 4 * 4 + 3 * 128 * 2;
     // prefetch 256 positions per head whatever the split: PRE runs of 16 on each of the 4*S waves
     int dh = 1;
@@ -693,13 +699,14 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
         const uint32_t packed = (uint32_t)n_heads | ((uint32_t)n_kv << 12) | ((uint32_t)S << 24) | ((tab_rows == 1 ? 1u : 0u) << 28);
         hipLaunchKernelGGL(kern, dim3(n_heads * S * dh), dim3(256), smem, st, pos, out_pos, (const f16*)q, (const f16*)k,
                            (const f16*)v, (const float*)cs, packed, (const float*)sn, (f16*)kc, (f16*)vc, (f16*)out, (float*)ws,
-                           max_seq, g_attn_dbg);
+                           max_seq, g_attn_dbg, alibi_slopes);
         return hipGetLastError();
     };
     // measured on the 7B decode step (contexts 64..192): 682 / 689 / 688 tokens/s with 1 / 2 / 4 blocks per head
     static const int dh_env = getenv("QEFT_ATTN_DH") ? atoi(getenv("QEFT_ATTN_DH")) : 2;   // A/B switch: 1, 2 or 4 (4: 797 vs 799 tokens/s)
     if (k_ft_layout) {     // the reference's single_query_attention boundary: one block per head
         if (S != 1) return hipErrorInvalidValue;
+        if (alibi_slopes) return launch(rope_attn_decode_kernel<4, 1, true, false, true>);
         return launch(rope_attn_decode_kernel<4, 1, true>);
     }
     if (g_attn_dbg) {      // lab: the stamped variants

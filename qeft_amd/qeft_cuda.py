@@ -384,17 +384,23 @@ def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_
     """ft_attention.cpp:110-181 with the reference's positional signature and cache layouts:
         q [B, H, 128], k / v [B, Hkv, 128] fp16 (last-dim stride 1, head stride 128)
         k_cache [B, Hkv, 128/8, L, 8], v_cache [B, Hkv, L, 128] fp16 contiguous
-    Rotates q / k at position `timestep` (neox style, rotary_embedding_dim in {0, 128}), appends k / v to the caches at
-    that position and returns softmax(q K^T / sqrt(128)) V as a new tensor shaped like q.  length_per_sample_ (int32 [B],
-    optional): per-sample position instead of `timestep` (ft_attention.cpp:143-149).
-    Not supported (RuntimeError): ALiBi slopes, head sizes other than 128, interleaved (GPT-J) rotary, fp32 / bf16."""
+    Rotates q / k at position `timestep`, appends k / v to the caches at that position and returns
+    softmax(q K^T / sqrt(128) [+ alibi]) V as a new tensor shaped like q.  length_per_sample_ (int32 [B], optional): per-sample
+    position instead of `timestep` (ft_attention.cpp:143-149).  alibi_slopes_ (fp32 [H], optional): slope * (key - query
+    position) added to the scaled scores (decoder_masked_multihead_attention_template.hpp:1335-1345).
+    Rotary: the neox style over the whole head (Llama: rotary_embedding_dim 128) or none (0) runs inside the kernel; a partial
+    rotary_embedding_dim (even, < 128) and the interleaved GPT-J style (neox_rotary_style=False) are rotated here with a few
+    torch ops (fp32 math, rounded to half as the reference's kernel does) in front of a launch without rotary.
+    Not supported (RuntimeError): head sizes other than 128, fp32 / bf16."""
     _need(q.is_cuda and q.dtype == torch.float16, "single_query_attention: only Half GPU tensors are supported")
-    _need(alibi_slopes_ is None, "single_query_attention: ALiBi is not supported by the MI355X build")
-    _need(neox_rotary_style, "single_query_attention: only neox-style (non-interleaved) rotary is supported")
     B, Hkv, L, D = v_cache.shape
     H = q.shape[1]
     _need(D == 128, "single_query_attention: head_dim must be 128")
-    _need(rotary_embedding_dim in (0, D), "single_query_attention: rotary_embedding_dim must be 0 or head_dim")
+    rot = int(rotary_embedding_dim)
+    _need(0 <= rot <= D and rot % 2 == 0, "single_query_attention: rotary_embedding_dim must be an even number in [0, head_dim]")
+    if alibi_slopes_ is not None:
+        _need(alibi_slopes_.is_cuda and alibi_slopes_.dtype == torch.float32 and alibi_slopes_.is_contiguous()
+              and alibi_slopes_.numel() == H, "alibi_slopes_ must be a contiguous Float [n_heads] GPU tensor")
     _need(tuple(q.shape) == (B, H, D) and tuple(k.shape) == (B, Hkv, D) and tuple(v.shape) == (B, Hkv, D), "bad q/k/v shape")
     _need(tuple(k_cache.shape) == (B, Hkv, D // 8, L, 8), "k_cache must be [B, Hkv, Dh/8, L, 8]")
     _need(k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.dtype == torch.float16
@@ -410,14 +416,36 @@ def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_
     else:
         _need(0 <= int(timestep) < L, f"timestep {timestep} outside the cache (length {L})")
         pos = torch.full((B,), int(timestep), dtype=torch.int32, device=q.device)
-    tab = _rope_table(q.device, rotary_embedding_dim, rotary_base, L)
+    in_kernel = rot == 0 or (rot == D and neox_rotary_style)
+    if not in_kernel:
+        # rotate here: pairs (i, i + rot/2) (neox) or (2i, 2i + 1) (GPT-J) of the first `rot` dims, angle pos * base^(-2i/rot)
+        half = rot // 2
+        inv = 1.0 / (float(rotary_base) ** (torch.arange(0, half, dtype=torch.float64, device=q.device) * 2.0 / rot))
+        ang = pos.to(torch.float64)[:, None] * inv[None, :]
+        c, sn = ang.cos().float()[:, None, :], ang.sin().float()[:, None, :]
+
+        def rotate(t):
+            tf = t.float()
+            a, b_ = (tf[..., :half], tf[..., half:rot]) if neox_rotary_style else (tf[..., 0:rot:2], tf[..., 1:rot:2])
+            ra, rb = a * c - b_ * sn, b_ * c + a * sn
+            o = tf.clone()
+            if neox_rotary_style:
+                o[..., :half], o[..., half:rot] = ra, rb
+            else:
+                o[..., 0:rot:2], o[..., 1:rot:2] = ra, rb
+            return o.half().contiguous()
+        q, k = rotate(q), rotate(k)
+    tab = _rope_table(q.device, rot if in_kernel else 0, rotary_base, L)
     out = torch.empty_like(q)
     with torch.cuda.device(q.device):
         lib, st = _lib.lib(), _stream(q)
         for b in range(B):      # the kernel serves one sequence per launch (decode harness); the batch is a host loop
-            _lib.check(lib.qeft_single_query_attention(
-                q[b].data_ptr(), k[b].data_ptr(), v[b].data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), L,
-                k_cache[b].data_ptr(), v_cache[b].data_ptr(), pos.data_ptr() + 4 * b, out[b].data_ptr(), H, Hkv, L, st))
+            args = (q[b].data_ptr(), k[b].data_ptr(), v[b].data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), L,
+                    k_cache[b].data_ptr(), v_cache[b].data_ptr(), pos.data_ptr() + 4 * b, out[b].data_ptr(), H, Hkv, L)
+            if alibi_slopes_ is None:
+                _lib.check(lib.qeft_single_query_attention(*args, st))
+            else:
+                _lib.check(lib.qeft_single_query_attention_alibi(*args, alibi_slopes_.data_ptr(), st))
     return out
 
 

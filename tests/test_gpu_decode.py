@@ -399,32 +399,45 @@ def test_shim_layernorm_forward_cuda():
         qeft_cuda.layernorm_forward_cuda(x.float(), gamma, out, 1e-5)
 
 
-@pytest.mark.parametrize("B,H,Hkv,rot", [(1, 4, 4, 128), (2, 8, 2, 128), (1, 2, 2, 0)])
-def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot):
+@pytest.mark.parametrize("B,H,Hkv,rot,neox,alibi", [(1, 4, 4, 128, True, False), (2, 8, 2, 128, True, False), (1, 2, 2, 0, True, False),
+                                                     (2, 4, 2, 128, True, True), (1, 4, 4, 0, True, True), (2, 4, 2, 64, True, False),
+                                                     (1, 4, 4, 128, False, False), (2, 4, 4, 32, False, True)])
+def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot, neox, alibi):
     """Positional call exactly as ftllama_modeling.py:139-153 makes it, caches in the reference's layouts
-    (k_cache [B, Hkv, Dh/8, L, 8], v_cache [B, Hkv, L, Dh]); checked against a plain fp32 PyTorch decode."""
+    (k_cache [B, Hkv, Dh/8, L, 8], v_cache [B, Hkv, L, Dh]); checked against a plain fp32 PyTorch decode -- the neox rotary
+    of the Llama path, no rotary, a partial rotary_embedding_dim, the interleaved GPT-J style
+    (decoder_masked_multihead_attention_utils.h: pairs (2i, 2i + 1), angle t / base^(2i / rot)) and ALiBi slopes
+    (decoder_masked_multihead_attention_template.hpp:1335-1345: slope * (key - query position) on the scaled score)."""
     import math
     import qeft_cuda
     D, L, T = 128, 64, 21
     torch.manual_seed(B * 10 + H)
     k_cache = torch.zeros(B, Hkv, D // 8, L, 8, dtype=torch.float16, device=DEV)
     v_cache = torch.zeros(B, Hkv, L, D, dtype=torch.float16, device=DEV)
-    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, dtype=torch.float64) / 64))
+    half = max(rot // 2, 1)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, half, dtype=torch.float64) * 2.0 / max(rot, 1)))
+    slopes = (2.0 ** (-8.0 * torch.arange(1, H + 1, dtype=torch.float32) / H)).to(DEV) if alibi else None
 
-    def rope(x, p):       # [.., 128] fp32, neox style
+    def rope(x, p):       # [.., 128] fp32: the first `rot` dims rotated, neox pairs (i, i + rot/2) or GPT-J pairs (2i, 2i + 1)
         if rot == 0:
             return x
         ang = (p * inv).float().to(x.device)
         c, s = ang.cos(), ang.sin()
-        a, b = x[..., :64], x[..., 64:]
-        return torch.cat([a * c - b * s, b * c + a * s], -1)
+        o = x.clone()
+        if neox:
+            a, b = x[..., :half], x[..., half:rot]
+            o[..., :half], o[..., half:rot] = a * c - b * s, b * c + a * s
+        else:
+            a, b = x[..., 0:rot:2], x[..., 1:rot:2]
+            o[..., 0:rot:2], o[..., 1:rot:2] = a * c - b * s, b * c + a * s
+        return o
 
     ks, vs = [], []
     for t in range(T):
         q = torch.randn(B, H, D, device=DEV).half()
         k = torch.randn(B, Hkv, D, device=DEV).half()
         v = torch.randn(B, Hkv, D, device=DEV).half()
-        out = qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, t, rot, 10000.0, True)
+        out = qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, slopes, t, rot, 10000.0, neox)
         torch.cuda.synchronize()
         assert out.shape == q.shape and out.dtype == torch.float16
         ks.append(rope(k.float(), t).half().float())
@@ -432,6 +445,8 @@ def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot):
         K, V = torch.stack(ks, 2), torch.stack(vs, 2)                          # [B, Hkv, t+1, D]
         K, V = K.repeat_interleave(H // Hkv, 1), V.repeat_interleave(H // Hkv, 1)
         att = torch.einsum("bhd,bhtd->bht", rope(q.float(), t), K) / math.sqrt(D)
+        if alibi:
+            att = att + slopes[None, :, None] * (torch.arange(t + 1, device=DEV, dtype=torch.float32) - t)[None, None, :]
         ref = torch.einsum("bht,bhtd->bhd", att.softmax(-1), V)
         assert (out.float() - ref).abs().max().item() < 2e-2 * max(ref.abs().max().item(), 1.0), t
     # the caches hold what the reference's would: rotated keys in the FT layout, values as they came
@@ -440,16 +455,16 @@ def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot):
     assert torch.equal(v_cache[:, :, :T].float(), torch.stack(vs, 2))
     assert float(k_cache.permute(0, 1, 3, 2, 4).reshape(B, Hkv, L, D)[:, :, T:].abs().max()) == 0.0
     # unsupported arguments raise (documented in the shim)
-    with pytest.raises(RuntimeError, match="ALiBi"):
-        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, torch.zeros(H, device=DEV), T, rot, 10000.0, True)
-    with pytest.raises(RuntimeError, match="neox"):
-        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, T, rot, 10000.0, False)
+    with pytest.raises(RuntimeError, match="alibi_slopes_"):
+        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, torch.zeros(H + 1, device=DEV), T, rot, 10000.0, neox)
+    with pytest.raises(RuntimeError, match="rotary_embedding_dim"):
+        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, T, 63, 10000.0, neox)
     with pytest.raises(RuntimeError, match="timestep"):
-        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, L, rot, 10000.0, True)
+        qeft_cuda.single_query_attention(q, k, v, k_cache, v_cache, None, None, L, rot, 10000.0, neox)
     # per-sample lengths instead of the common timestep (ft_attention.cpp:143-149)
     lens = torch.full((B,), T, dtype=torch.int32, device=DEV)
-    o1 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), lens, None, 0, rot, 10000.0, True)
-    o2 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), None, None, T, rot, 10000.0, True)
+    o1 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), lens, slopes, 0, rot, 10000.0, neox)
+    o2 = qeft_cuda.single_query_attention(q, k, v, k_cache.clone(), v_cache.clone(), None, slopes, T, rot, 10000.0, neox)
     torch.cuda.synchronize()
     assert torch.equal(o1, o2)
 
