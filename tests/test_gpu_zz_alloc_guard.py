@@ -146,6 +146,19 @@ for (n, k, r, g, m, gather) in [(16, 256, 128, 128, 1, True), (16, 256, 128, 128
                                 (16 * 257, 256, 128, 128, 3, False), (32, 4096, 128, 4096, 2, True), (16, 11008, 128, 128, 7, False)]:
     gemv(n, k, r, g, m, gather=gather)
     assert _lib.last_variant().startswith("gemv_v3"), (_lib.last_variant(), n, k, r, g, m)
+# ---- round 3: 8..16 rows at the GEMM entries ride on the decode GEMV -- x rows staged in LDS (gemv_v3_mb) or read by the lanes from
+#      global memory (gemv_v3_mb_xg: rows * K * 2 bytes exceed the LDS); one row set, a last block with fewer sets, per-channel scales
+for (n, k, r, g, m, want) in [(16, 256, 128, 128, 16, "gemv_v3_mb"), (48, 384, 0, 128, 9, "gemv_v3_mb"), (16 * 257, 256, 128, 128, 12, "gemv_v3_mb"),
+                              (32, 11008, 128, 128, 16, "gemv_v3_mb_xg"), (16, 13824, 0, 128, 8, "gemv_v3_mb_xg"),
+                              (64, 4096, 128, 4096, 16, "gemv_v3_mb"), (16 * 9, 11008, 128, 11008, 11, "gemv_v3_mb_xg")]:
+    b = O.make_layer(n, k, r, g, seed=n + k + m)
+    t = layer_to_torch(b, DEV)
+    x = O.make_activation(m, k, r, seed=m)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t.get("oweight") if r else None)
+    assert _lib.last_variant() == want, (_lib.last_variant(), n, k, r, g, m)
+    torch.cuda.synchronize()
+    ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, None, g)
+    assert rel_err(y.cpu().numpy(), ref.astype(np.float64)) < 1e-3, ("rows16", n, k, r, g, m)
 lib = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 hh = torch.randn(512, device=DEV); gg = torch.ones(512, device=DEV).half(); ww = (torch.randn(7, 512, device=DEV) * 0.05).half()
