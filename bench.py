@@ -401,15 +401,15 @@ def mid_m_records(dev, ms=(16, 64, 512, 1024), layers=4, reps=25):
     return recs
 
 
-def model_13b_record(dev, steps=128, warmup=64):
+def model_13b_record(dev, steps=128, warmup=64, base=None):
     """model_13b: BASELINE config 4's model (Llama-2-13B shapes, w4 g128 r128) on ONE GPU with the headline protocol
     (64-token context, `warmup` untimed tokens, `steps` timed graph-replayed tokens) and the GEMV launches' rate -- the
-    single-GPU point of the row-sharded curve; compact on purpose."""
+    single-GPU point of the row-sharded curve; compact on purpose.  `base`: another model shape (the N > 1 line's replica figure)."""
     import dataclasses
     import torch
     from qeft_amd.llama import LLAMA2_13B, DecodeEngine, QuantLlama
     ctx0 = CONTEXT + warmup
-    shape = dataclasses.replace(LLAMA2_13B, max_seq=512)
+    shape = dataclasses.replace(base if base is not None else LLAMA2_13B, max_seq=512)
     model = QuantLlama(shape, dev, seed=0, fast_init=True)
     eng = DecodeEngine(model, use_graph=True)
     eng.greedy = True
@@ -656,6 +656,23 @@ def main():
             multi = dict(multi or {}, error=f"{type(e).__name__}: {e}"[:300])
             if rank == 0:
                 print(f"[bench] multi-GPU diagnostics failed: {type(e).__name__}: {e}", file=sys.stderr)
+        # ---- the other way to use N GPUs for a model that fits one: N independent replicas of the single-GPU engine, one sequence
+        # each, no collective (what a server does at batch 1 per GPU).  Every rank measures its own replica (no collective inside
+        # the measurement: a rank that fails reports None and nobody waits for it); the line carries the sum beside `value`.
+        mine = None
+        if world > 1 and not args.no_extras:
+            try:
+                r = model_13b_record(dev, steps=max(32, min(args.steps, 128)), warmup=16, base=base)
+                mine = {"rank": rank, "tokens_per_s": r["tokens_per_s"], "gemv_frac_of_8TB/s": r["gemv_frac_of_8TB/s"]}
+            except Exception as e:
+                mine = {"rank": rank, "error": f"{type(e).__name__}: {e}"[:200]}
+            reps = [None] * world
+            dist.all_gather_object(reps, mine)
+            ok = [x["tokens_per_s"] for x in reps if x and "tokens_per_s" in x]
+            multi = dict(multi or {}, replicas={"tokens_per_s_sum": round(sum(ok), 1), "ranks_measured": len(ok), "per_rank": reps,
+                                               "shared_device": bool(shared),
+                                               "note": "N independent single-GPU engines (one sequence each, no collective), each rank timed "
+                                                       "on its own; `value` above is ONE sequence decoded by all N ranks (tensor parallel)"})
     tp3 = bool(getattr(eng, "tp3", False))      # (the extras below free the engine)
     extras = {}
     if world == 1 and not args.no_extras:
