@@ -143,7 +143,7 @@ def cpu_baseline(shape, budget_s=24.0):
 
 
 # ---------------------------------------------------------------------------------------------------- PMC child run
-def hbm_traffic_per_gemv_launch(model_flag, bits):
+def hbm_traffic_per_gemv_launch(model_flag, bits, ckpt=None):
     """HBM bytes per GEMV launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes: a run of its own
     under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (nothing else traced), a short CHILD run of this script started
     before this process touches the GPU; FETCH_SIZE is in KiB and, on gfx950, reports half of the bytes of a wide
@@ -162,6 +162,8 @@ def hbm_traffic_per_gemv_launch(model_flag, bits):
     try:
         cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "run", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--model", model_flag, "--bits", str(bits)]
+        if ckpt:        # the counters must describe the launches of the model the line is about
+            cmd += ["--ckpt", os.path.abspath(ckpt)]
         env = dict(os.environ, TMPDIR="/tmp")
         res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
         if res.returncode != 0:
@@ -401,7 +403,7 @@ def mid_m_records(dev, ms=(16, 64, 512, 1024), layers=4, reps=25):
     return recs
 
 
-def model_13b_record(dev, steps=128, warmup=64, base=None):
+def model_13b_record(dev, steps=128, warmup=64, base=None, bits=4):
     """model_13b: BASELINE config 4's model (Llama-2-13B shapes, w4 g128 r128) on ONE GPU with the headline protocol
     (64-token context, `warmup` untimed tokens, `steps` timed graph-replayed tokens) and the GEMV launches' rate -- the
     single-GPU point of the row-sharded curve; compact on purpose.  `base`: another model shape (the N > 1 line's replica figure)."""
@@ -409,7 +411,7 @@ def model_13b_record(dev, steps=128, warmup=64, base=None):
     import torch
     from qeft_amd.llama import LLAMA2_13B, DecodeEngine, QuantLlama
     ctx0 = CONTEXT + warmup
-    shape = dataclasses.replace(base if base is not None else LLAMA2_13B, max_seq=512)
+    shape = dataclasses.replace(base if base is not None else LLAMA2_13B, max_seq=512, bits=bits)
     model = QuantLlama(shape, dev, seed=0, fast_init=True)
     eng = DecodeEngine(model, use_graph=True)
     eng.greedy = True
@@ -432,7 +434,7 @@ def model_13b_record(dev, steps=128, warmup=64, base=None):
     nbytes = eng.weight_bytes_per_token() / launches
     rec = {"tokens_per_s": round(steps / dt, 2), "ms_per_step": round(dt * 1e3 / steps, 4), "steps": steps,
            "gemv_us_per_launch": round(us, 3), "gemv_bytes_per_launch": int(nbytes), "gemv_GB/s": round(nbytes / us / 1e3, 1),
-           "gemv_frac_of_8TB/s": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "workload": f"{shape.name} w4 g128 r128, batch 1, one GPU"}
+           "gemv_frac_of_8TB/s": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "workload": f"{shape.name} w{shape.bits} g{shape.group_size} r{shape.n_out}, batch 1, one GPU"}
     del eng, g2, model
     torch.cuda.empty_cache()
     return rec
@@ -450,7 +452,7 @@ def main():
     # the PMC pass is a child process of its own and has to start BEFORE this process initialises the GPU
     traffic = None
     if world == 1 and "RANK" not in os.environ and not args.no_traffic and not args.pmc_child:
-        traffic = hbm_traffic_per_gemv_launch(args.model, args.bits)
+        traffic = hbm_traffic_per_gemv_launch(args.model, args.bits, args.ckpt)
 
     import torch
     import torch.distributed as dist
@@ -662,7 +664,7 @@ def main():
         mine = None
         if world > 1 and not args.no_extras:
             try:
-                r = model_13b_record(dev, steps=max(32, min(args.steps, 128)), warmup=16, base=base)
+                r = model_13b_record(dev, steps=max(32, min(args.steps, 128)), warmup=16, base=base, bits=args.bits)
                 mine = {"rank": rank, "tokens_per_s": r["tokens_per_s"], "gemv_frac_of_8TB/s": r["gemv_frac_of_8TB/s"]}
             except Exception as e:
                 mine = {"rank": rank, "error": f"{type(e).__name__}: {e}"[:200]}

@@ -30,16 +30,27 @@ def save_packed(model, quantinfos, save_path):
                 "dtype": torch.float16, "bits": first.bits, "group_size": first.group_size}, save_path)
 
 
-def load_packed(model, checkpoint_path, device="cuda:0", training=False):
+def load_checkpoint_file(checkpoint_path, unsafe_pickle=False):
+    """torch.load of a checkpoint in the reference's format (save_model / save_wctmodel, modelutils.py:248-284).  The only
+    non-tensor objects the format holds are argparse.Namespace instances (`quantinfos`) and a torch.dtype, so the file is read with
+    the restricted unpickler plus that one class; the reference's own `torch.load` runs arbitrary pickle code, which a
+    user-supplied .pth (bench.py --ckpt) must not.  unsafe_pickle=True is the reference's behaviour, for files that carry more."""
+    if unsafe_pickle:
+        return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    import argparse
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        return torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+
+
+def load_packed(model, checkpoint_path, device="cuda:0", training=False, unsafe_pickle=False):
     """reference load_owqmodel / hfmodel_to_owqmodel (modelutils.py:120-183): swap modules, load buffers
-    (strict=False like the reference), bind kernels.  The pickle holds argparse.Namespace objects, hence
-    weights_only=False (torch >= 2.6)."""
-    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    (strict=False like the reference), bind kernels."""
+    ckpt = load_checkpoint_file(checkpoint_path, unsafe_pickle)
     if "base_path" in ckpt:
         base = ckpt["base_path"]
         if not os.path.isabs(base) and not os.path.exists(base):     # a delta that travelled with its base file
             base = os.path.join(os.path.dirname(os.path.abspath(checkpoint_path)), base)
-        model = load_packed(model, base, device=device, training=training)
+        model = load_packed(model, base, device=device, training=training, unsafe_pickle=unsafe_pickle)
         replace_oweight(model, ckpt["oweight_state_dict"])
         return model
     assert ckpt.get("packing", False), "not a packed checkpoint"

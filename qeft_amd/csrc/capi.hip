@@ -282,7 +282,7 @@ static int gemm_impl(const void* x, const void* qweight, const void* scales, con
         if (r != V3_NOT_TAKEN) return r;
     }
     if (small_m_route(m, n, workspace != nullptr && workspace_bytes > 0) && (n_out > 0) == (oweight != nullptr) &&
-        !(v3_route_enabled() && n % 16 == 0 && qeft::gemv_v3_ok(k, group_size, n_out))) {
+        !(m <= qeft::V3_MAX_M && v3_route_enabled() && n % 16 == 0 && qeft::gemv_v3_ok(k, group_size, n_out))) {
         // few rows: stream the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
         // (gemm_4bit semantics with oweight == NULL and a non-zero slice -- dead nibbles -- stays on the GEMM kernel.)
         qeft::GemvArgs a{};

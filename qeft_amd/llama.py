@@ -150,22 +150,25 @@ class QuantLlama(nn.Module):
 
     # ------------------------------------------------------------------ packed checkpoint -> model
     @classmethod
-    def from_packed(cls, checkpoint_path, device="cuda:0", max_seq=512, rms_eps=1e-5, rope_theta=10000.0, name=None):
+    def from_packed(cls, checkpoint_path, device="cuda:0", max_seq=512, rms_eps=1e-5, rope_theta=10000.0, name=None,
+                    n_heads=None, n_kv_heads=None, unsafe_pickle=False):
         """A packed checkpoint in the reference's on-disk format (save_model, qeft/utils/modelutils.py:248-268) as a QuantLlama
         the DecodeEngine / prefill / eval_nll run on -- the counterpart of load_owqmodel (modelutils.py:147-183) feeding the
         reference's decode benchmark (qeft/main.py:310-371, 510-553).  The state dict carries HF's LlamaForCausalLM keys
         (`model.embed_tokens.weight`, `model.layers.i.self_attn.q_proj.qweight` ..., `model.layers.i.input_layernorm.weight`,
         `model.norm.weight`, `lm_head.weight`); the shape is read off the tensors (head_dim 128: Llama-2 7B / 13B; HF hub
-        loading and config.json are out of scope, so rms_eps / rope_theta / max_seq are arguments).  A fine-tuned delta
+        loading is out of scope, so rms_eps / rope_theta / max_seq are arguments; a `config.json` beside the checkpoint, or the
+        n_heads / n_kv_heads arguments, say how the projections split into heads -- without either, head_dim 128 is assumed, with
+        a warning outside the Llama-2 shapes; a split that is not head_dim 128 raises rather than decode with the wrong rotary).
+        A fine-tuned delta
         (`{oweight_state_dict, base_path}`, save_wctmodel :270-284) loads its base first and replaces the outlier slices."""
-        from argparse import Namespace  # noqa: F401  (the pickle holds argparse.Namespace objects)
-        from .checkpoint import replace_oweight
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        from .checkpoint import replace_oweight, load_checkpoint_file
+        ckpt = load_checkpoint_file(checkpoint_path, unsafe_pickle)
         if "base_path" in ckpt:
             base = ckpt["base_path"]
             if not os.path.isabs(base) and not os.path.exists(base):
                 base = os.path.join(os.path.dirname(os.path.abspath(checkpoint_path)), base)
-            model = cls.from_packed(base, device, max_seq, rms_eps, rope_theta, name)
+            model = cls.from_packed(base, device, max_seq, rms_eps, rope_theta, name, n_heads, n_kv_heads, unsafe_pickle)
             replace_oweight(model, ckpt["oweight_state_dict"])
             return model
         assert ckpt.get("packing", False), "not a packed checkpoint"
@@ -175,9 +178,30 @@ class QuantLlama(nn.Module):
         info0 = infos["model.layers.0.self_attn.q_proj"]
         kv = sd["model.layers.0.self_attn.k_proj.scales"].shape[1]
         inter = sd["model.layers.0.mlp.gate_proj.scales"].shape[1]
-        assert hidden % 128 == 0 and kv % 128 == 0, "the decode attention kernel is built for head_dim 128"
+        # head split: explicit arguments > config.json beside the file (HF keys) > the known Llama-2 shapes
+        cfg_path = os.path.join(os.path.dirname(os.path.abspath(checkpoint_path)), "config.json")
+        if n_heads is None and os.path.exists(cfg_path):
+            import json
+            with open(cfg_path) as fh:
+                cfg = json.load(fh)
+            n_heads = int(cfg["num_attention_heads"])
+            n_kv_heads = int(cfg.get("num_key_value_heads", n_heads))
+            rms_eps = float(cfg.get("rms_norm_eps", rms_eps))
+            rope_theta = float(cfg.get("rope_theta", rope_theta))
+        if n_heads is None:
+            if hidden % 128 or kv % 128:
+                raise ValueError(f"cannot infer the head split of hidden={hidden}, kv={kv}: pass n_heads / n_kv_heads or put config.json beside the checkpoint")
+            if (hidden, inter) not in ((4096, 11008), (5120, 13824), (8192, 28672)):
+                import warnings
+                warnings.warn(f"{checkpoint_path}: no config.json and no n_heads given; head_dim 128 assumed for hidden={hidden}")
+            n_heads = hidden // 128
+        if n_kv_heads is None:
+            n_kv_heads = kv // (hidden // n_heads)
+        if hidden % n_heads or hidden // n_heads != 128 or kv != n_kv_heads * 128:
+            raise ValueError(f"head_dim {hidden // n_heads if hidden % n_heads == 0 else hidden / n_heads} (hidden {hidden}, "
+                             f"{n_heads} heads, kv width {kv}): the decode attention kernel is built for head_dim 128 only")
         gs = info0.group_size if info0.group_size and info0.group_size > 0 else hidden
-        shape = LlamaShape(hidden, inter, n_layers, hidden // 128, kv // 128, vocab, max_seq, rms_eps, rope_theta,
+        shape = LlamaShape(hidden, inter, n_layers, n_heads, n_kv_heads, vocab, max_seq, rms_eps, rope_theta,
                            n_out=int(info0.n_out), group_size=int(gs), name=name or os.path.basename(checkpoint_path),
                            bits=int(info0.bits))
         self = cls.__new__(cls)

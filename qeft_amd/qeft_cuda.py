@@ -33,6 +33,7 @@ def _check_common(in_feats, kernel, scales, zeros):
 
 def gemv_4bit(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size):
     """gemv_cuda.cu:358-525.  m in 1..7 else RuntimeError("Unsupported batch size for gemv kernel.")."""
+    _need(1 <= int(m) <= 7, "Unsupported batch size for gemv kernel.")
     _check_common(in_feats, kernel, scaling_factors, zeros)
     x = in_feats.contiguous()
     _need(x.numel() == m * k, f"in_feats has {x.numel()} elements, expected m*k = {m * k}")
@@ -45,7 +46,9 @@ def gemv_4bit(in_feats, kernel, scaling_factors, zeros, m, n, k, group_size):
 
 
 def gemv_4bit_qeft(in_feats, kernel, scaling_factors, zeros, oweight, m, n, k, group_size):
-    """gemv_cuda_qeft.cu:392-513.  `oweight` is the interleaved [N/2, 2r] buffer; r = oweight.size(1)/2 (:424)."""
+    """gemv_cuda_qeft.cu:392-513.  `oweight` is the interleaved [N/2, 2r] buffer; r = oweight.size(1)/2 (:424).
+    m outside 1..7: RuntimeError("Unsupported batch size for gemv kernel.") (:466)."""
+    _need(1 <= int(m) <= 7, "Unsupported batch size for gemv kernel.")
     _check_common(in_feats, kernel, scaling_factors, zeros)
     _need(oweight.dtype == torch.float16 and oweight.is_contiguous() and oweight.device == in_feats.device,
           "oweight_interleaved must be a contiguous Half tensor on the input's device")
@@ -322,7 +325,15 @@ def gemm_3bit_dx(grad_out, qweight3, scales, zeros, oweights, k):
     n = qweight3.shape[0] * 16
     m = dy.numel() // n
     n_out = oweights.shape[1] if oweights is not None else 0
+    # (the C entry walks (k - n_out) / 128 steps of 192 ints per 16-row set: a wrong k, or oweights=None on a layer packed with
+    #  r > 0, would read past the 3-bit buffer)
+    _need(qweight3.dtype == torch.int32 and qweight3.is_contiguous(), "qweight3 must be a contiguous Int tensor")
+    _need(qweight3.shape[1] == (k - n_out) // 128 * 192, f"qweight3 has {qweight3.shape[1]} columns, expected {(k - n_out) // 128 * 192}")
+    _need(scales.shape[0] > 0 and k % scales.shape[0] == 0, f"scales has {scales.shape[0]} groups for k = {k}")
     group = k // scales.shape[0]
+    _need(tuple(scales.shape) == (k // group, n) and tuple(zeros.shape) == (k // group, n),
+          f"scales / zeros must be [{k // group}, {n}], got {tuple(scales.shape)} / {tuple(zeros.shape)}")
+    _need(qweight3.data_ptr() % 16 == 0, "qweight3 must be 16-byte aligned")
     lib = _lib.lib()
     if m == 0 or not lib.qeft_gemm_w3_dx_supported(m, n, k, group, n_out):
         return gemm_4bit_dx(grad_out, expand_3bit(qweight3, n, k, n_out), scales, zeros, oweights)

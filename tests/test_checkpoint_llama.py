@@ -153,3 +153,45 @@ def test_replace_oweight_reaches_prefill_and_stops_a_stale_engine():
     eng2 = DecodeEngine(model, use_graph=False)
     got = eng2.teacher_forced_logits(tokens)
     assert (got - ref).abs().max().item() / ref.abs().max().item() < 5e-3
+
+
+def test_from_packed_head_split_is_explicit_or_refused(tmp_path):
+    """hidden % 128 == 0 does not make head_dim 128.  An explicit n_heads (or a config.json beside the file) that gives
+    another head size must raise instead of decoding with the wrong head split / rotary."""
+    import json
+    import shutil
+    import warnings
+    from qeft_amd.llama import QuantLlama
+    ck = torch.load(CKPT, map_location="cpu", weights_only=False)
+    hidden = ck["model_state_dict"]["model.embed_tokens.weight"].shape[1]
+    with pytest.raises(ValueError, match="head_dim"):
+        QuantLlama.from_packed(CKPT, device="cpu", max_seq=64, n_heads=hidden // 64, n_kv_heads=hidden // 64)
+    p = tmp_path / "m.pth"
+    shutil.copy(CKPT, p)
+    (tmp_path / "config.json").write_text(json.dumps({"num_attention_heads": hidden // 64, "num_key_value_heads": hidden // 64}))
+    with pytest.raises(ValueError, match="head_dim"):
+        QuantLlama.from_packed(str(p), device="cpu", max_seq=64)
+    (tmp_path / "config.json").write_text(json.dumps({"num_attention_heads": hidden // 128, "rms_norm_eps": 1e-6, "rope_theta": 5e5}))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # config present: nothing is assumed, nothing warned
+        m = QuantLlama.from_packed(str(p), device="cpu", max_seq=64)
+    assert m.shape.n_heads == hidden // 128 and m.shape.rms_eps == 1e-6 and m.shape.rope_theta == 5e5
+
+
+def test_checkpoint_files_load_with_the_restricted_unpickler():
+    """The format's only non-tensor objects are argparse.Namespace and a dtype: no arbitrary pickle code is needed (or run)."""
+    from qeft_amd.checkpoint import load_checkpoint_file
+    a = load_checkpoint_file(CKPT)
+    b = load_checkpoint_file(CKPT, unsafe_pickle=True)
+    assert a.keys() == b.keys() and a["quantinfos"].keys() == b["quantinfos"].keys()
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("arbitrary code ran",))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "evil.pth")
+        torch.save({"model_state_dict": {}, "x": Evil()}, path)
+        with pytest.raises(pickle.UnpicklingError):
+            load_checkpoint_file(path)
