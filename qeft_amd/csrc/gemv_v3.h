@@ -70,18 +70,6 @@ struct V3Geom {
     int K, n_out, nsteps, nfull, ngroups, nsets;   // nsets = N / 16
 };
 
-// LAB ONLY (-DQEFT_LAB, tools/gemv_v3_lab.hip): the NEXT launch's ring head, for the cross-launch L2 warm-up experiment of round 3
-// (gemv_v3_kernel step 0; measured, not adopted: DESIGN.md section 6, profiles/r03_gemv_warm_lab.txt).  qw == NULL: nothing to warm.
-struct V3Prefetch {
-    const uint8_t* qw;      // the next launch's packed weights
-    uint32_t set_bytes;     // bytes of one 16-row set of it
-    uint32_t seg_stride;    // bytes between a set's segments (4-bit: the four row groups, K' * 2 apart; 3-bit: one segment)
-    uint32_t geom;          // nblk' | rsc' << 16 | log2(1 KB pieces per segment) << 20 | log2(segments per set) << 24
-    uint32_t sets;          // sets_q' | sets_r' << 16
-    uint32_t stride;        // THIS launch's grid rounded down to a multiple of 8 (block b also warms next-launch block b + stride)
-    uint32_t pace;          // pieces in flight (8 / 16 / 32 / 63) | start delay << 8 (units of ~1000 clocks; lab)
-};
-
 struct V3Args {
     const f16* x;           // [K] fp16, consumed as it is (xn_gamma == NULL), or the fp32 vector h [K] (xn_gamma != NULL)
     const f16* xn_gamma;    // optional: x is fp32 h and the launch itself stages fp16(h * xn_gamma) and applies rsqrt(mean h^2 + eps)
@@ -102,7 +90,7 @@ struct V3Args {
     float* y32;             // PLAIN with residual: [N]
     f16* ynorm;
     float* ssq_out;
-    long long* dbg;         // lab only (ABL & 8): per block 8 x 100 MHz time stamps of wave 0; never read in the product
+    long long* dbg;         // lab hook (V3_STAMP_FLUSH): per block 8 x 100 MHz time stamps of wave 0; NULL and never read in the product
     int bits;               // 4 (0 is taken as 4), or 3: qw is the 3-bit extension layout int32 [N/16][nfull * 192]
     // ---- the reference's entry points (gemv_4bit[_qeft], QuantLinear.forward for < 8 rows): operands as the checkpoint holds them
     const f16* scales;      // with `zeros`: fp16 [K/g][N] each, used when szp == NULL (staged raw, packed in LDS)
@@ -112,9 +100,6 @@ struct V3Args {
     int m;                  // batch rows 1..16 (0 is taken as 1); x is [m][K], y [m][N]; m > 1: PLAIN, no residual / ssq_in / xn
     int nw;                 // waves per block chosen by the launcher (LDS sizing)
     bool xg;                // m > 1: the lanes read their x fragments from global memory (no x rows in LDS): any K with 16 rows
-#if defined(QEFT_LAB)
-    V3Prefetch pf;          // the next launch's ring head (warm-up experiment)
-#endif
 };
 
 // What the kernel receives.  The first 16 dwords of the kernel-argument segment -- the four operand pointers and the
@@ -134,16 +119,9 @@ struct V3Tail {
     const int* ids;
     int n_out, nsteps, nsets, n_ssq_in;
     float eps;
-#if defined(QEFT_LAB)
-    V3Prefetch pf;
-#endif
 };
 inline V3Tail v3_tail(const V3Args& a) {
-#if defined(QEFT_LAB)
-    return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.ids, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps, a.pf};
-#else
     return V3Tail{a.ssq_in, a.residual, a.gamma_out, a.bias, a.y, a.y32, a.ynorm, a.ssq_out, a.dbg, a.ids, a.g.n_out, a.g.nsteps, a.g.nsets, a.n_ssq_in, a.eps};
-#endif
 }
 inline uint32_t v3_flags(const V3Args& a) {
     const int m = a.m > 0 ? a.m : 1;
@@ -171,7 +149,7 @@ __host__ __device__ constexpr size_t v3_red_bytes(int rs_cap, int m = 1, int nw 
     return m > 1 ? ((size_t)rs_cap * nw * (m > 8 ? 16 : 8) * 16 * 4 + 1023) / 1024 * 1024 : ((size_t)rs_cap * V3_NW_MAX * 16 * 4 + 64 + 1023) / 1024 * 1024;
 }
 struct V3Lds {              // byte offsets of the regions inside the block's dynamic LDS
-    uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, pfl, total;
+    uint32_t xs, szl, owl, epl, ssql, red, xf, xg, szraw, idsl, xraw, total;
 };
 __host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_cap, int m, int nw, bool xn, bool szn, bool gather, bool xg = false) {
     V3Lds L;
@@ -187,10 +165,6 @@ __host__ __device__ inline V3Lds v3_lds(int K, int ngroups, int n_out, int rs_ca
     L.szraw = o; o += szn ? 2u * rs_cap * v3_szraw_bytes(ngroups) : 0u;                     // [2 arrays][rs_cap][groups][16] fp16
     L.idsl = o; o += gather ? (uint32_t)v3_xf_bytes(K) : 0u;                                // reorder_ids int32 [K]
     L.xraw = o; o += gather ? (uint32_t)m * v3_x_bytes(K) : 0u;                             // x rows before the gather
-    L.pfl = o;                                                                              // (lab) landing pad of the warm-up loads, never read
-#if defined(QEFT_LAB)
-    o += 4096;
-#endif
     L.total = o;
     return L;
 }
@@ -273,34 +247,15 @@ __device__ __forceinline__ void v3_dma16(const void* gsrc, uint32_t lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// N consecutive 1 KB pieces (N = 1, 2, 4) from gsrc, gsrc + 1024, .. by ONE asm statement (the instruction offset moves the
-// global and the LDS address alike): the warming wave's unit of work -- a wave issues an instruction every ~5 clocks at best,
-// so its loop must be a handful of instructions per piece
-template <int N> __device__ __forceinline__ void v3_dma16_run(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    if constexpr (N == 4)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    else if constexpr (N == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                     "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    else
-        v3_dma16(gsrc, lds_dst);
-}
-
-// In-kernel time stamps of the lab build (tools/gemv_v3_lab.hip, -DQEFT_LAB, ABL & 8); compiled out of the product
-// (the lab's blocks may carry one extra wave, the warming wave of the round-3 experiment)
-#if defined(QEFT_LAB)
-#define V3_LAUNCH_THREADS(nw) (((nw) + 1) * 64)
-#else
-#define V3_LAUNCH_THREADS(nw) ((nw) * 64)
-#endif
-#if defined(QEFT_LAB)
-#define V3_STAMP(i) do { if (ABL & 8) ts[i] = wall_clock64(); } while (0)
-#else
+// Lab hooks (tools/gemv_v3_lab.hip defines them before including this file; the product compiles them away): in-kernel time
+// stamps of wave 0 of every block, written through V3Args::dbg
+#if !defined(V3_STAMP)
+#define V3_STAMP_DECL
 #define V3_STAMP(i) do { } while (0)
+#define V3_STAMP_VALUE(v) do { } while (0)
+#define V3_STAMP_FLUSH() do { } while (0)
 #endif
+#define V3_LAUNCH_THREADS(nw) ((nw) * 64)
 
 // The value a lane accumulates per row set: batch row 0 only (MB == 1: D row 0 = register 0 of the lanes kc == 0), or the four
 // D rows 4 kc .. 4 kc + 3 of the lane (MB == 2: batch rows 0..7 live in the lanes kc < 2, rows 8..15 in the others)
@@ -330,7 +285,7 @@ __host__ __device__ constexpr int v3_unroll_steps(int D, int RSC) {
 }
 
 // NW waves per block (8, or 16 for launches of one block per CU: twice the instruction streams per SIMD for the same bytes);
-// wave w owns the 128-k steps w, w + NW, ...  ABL: lab ablations (tools/gemv_v3_lab.hip), 0 in the product.
+// wave w owns the 128-k steps w, w + NW, ...
 // MB: 1 = one batch row (the decode engine, and m = 1 at the reference's entry points); 2 = up to V3_MAX_M batch rows.
 // RSC: 16-row sets per block, a COMPILE-TIME constant (round 3): every (step, row set) of the wave's sequence then has its ring
 //      slot, accumulator and scale row fixed in the code -- the run-time bookkeeping of round 2's loop (which set is next, 0 / 1
@@ -339,7 +294,7 @@ __host__ __device__ constexpr int v3_unroll_steps(int D, int RSC) {
 //      stream their last set twice and drop the copy's results.
 // FL: the run-time flags (V3_F_*: per-channel scales, consumer-side norm, checkpoint-layout operands, gather) are honoured; false
 //     for the plain launches of the decode engine, which then carry no trace of those paths.
-template <int NW, int D, bool OUTL, int MODE, int ABL = 0, int BITS = 4, int MB = 1, int RSC = 1, bool FL = true, bool XG = false>
+template <int NW, int D, bool OUTL, int MODE, int BITS = 4, int MB = 1, int RSC = 1, bool FL = true, bool XG = false>
 __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const uint8_t* qw, const f16* x_in, const uint8_t* szp, const uint8_t* ow,
                                                           const f16* xn_gamma, int K_, uint32_t nblk_rscap_flags, uint32_t setsq_setsr,
                                                           V3Tail a) {
@@ -396,64 +351,8 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     int set0, RS;                                                     // RS = RSC, or RSC - 1 in a short block
     v3_block_sets(v3_xcd_block(blockIdx.x, nblk), sets_q, sets_r, set0, RS);
     auto set_of = [&](int rs) { return set0 + (rs < RS ? rs : RS - 1); };      // a short block's last slot repeats its last set
-#if defined(QEFT_LAB)
-    long long ts[7] = {0, 0, 0, 0, 0, 0, 0};    // ABL & 8: entry, ring issued, staging landed (barrier), steps done, (end), all waves done (barrier), values ready
-#endif
+    V3_STAMP_DECL
     V3_STAMP(0);
-
-#if defined(QEFT_LAB)
-    // ---- 0. LAB ONLY: the WARMING wave (launched as wave NW only when a.pf.qw is set): the cross-launch L2 warm-up experiment.
-    //         The weights of the NEXT launch do not depend on this one, but its first loads cannot be issued before it starts:
-    //         they pay a full HBM round trip behind the launch boundary while HBM idles.  Here one extra wave per block pulls
-    //         the next launch's RING HEAD (the first D loads of each of its waves: V3Prefetch) -- that of the next launch's
-    //         block with the same physical id, i.e. on the same XCD under the round-robin placement, the same L2 -- in whole
-    //         1 KB pieces by LDS-DMA into a landing pad nobody reads.  Measured (profiles/r03_gemv_warm_lab.txt): the follower
-    //         does start 0.7-0.9 us earlier (its staging barrier falls at 1.2 instead of 2.0-2.8 us), but the warming bytes
-    //         are moved, not saved, and cost the warming launch as much or more than they save the follower: -0.5 us per launch
-    //         on a chain of down_proj launches, +0.0 on o_proj, +0.3 on q|k|v, and +0.1 .. +1.2 us per launch on the engine's
-    //         real chain (where a 459-block gate|up launch also shifts the round-robin placement by 3 XCDs, so its
-    //         follower misses).  Issued from the streaming waves instead (behind their loop, or in front of their last round)
-    //         the same loads held every block's final barrier back by 1.2 us.  NOT in the product.
-    if (wave == NW) {
-        __builtin_amdgcn_s_barrier();                                                               // step 3
-        if (XN || GATHER || SZN) __builtin_amdgcn_s_barrier();                                      // step 3b
-        // (the descriptor into registers ONCE: behind an asm with a memory clobber hipcc re-reads kernel arguments from memory,
-        //  ~450 clocks per piece -- the first version of this loop ran at 4 GB/s per wave)
-        const uint8_t* const pq = a.pf.qw;
-        const uint32_t geom = a.pf.geom, setb = a.pf.set_bytes, segs = a.pf.seg_stride, sets2 = a.pf.sets, stride = a.pf.stride, pace = a.pf.pace;
-        asm volatile("" ::"s"(pq), "s"(geom), "s"(setb), "s"(segs), "s"(sets2), "s"(stride), "s"(pace));
-        const uint32_t nblk2 = geom & 0xffffu, rsc2 = (geom >> 16) & 15u, pps = 1u << ((geom >> 20) & 15u), sps = 1u << ((geom >> 24) & 15u);
-        const uint32_t q2 = sets2 & 0xffffu, r2 = sets2 >> 16, bid = blockIdx.x;
-        const uint32_t pad = __builtin_amdgcn_readfirstlane(lds0 + L.pfl);
-        for (uint32_t d = (pace >> 8) & 0xffu; d > 0; --d) __builtin_amdgcn_s_sleep(16);            // (lab knob: start later)
-        const uint32_t deep = pace & 0xffu;
-        for (uint32_t bb = bid, jj = 0; bb < nblk2 && jj < 2; bb += stride, ++jj) {                 // the next launch's blocks this block warms
-            int set0n, cntn;
-            v3_block_sets(v3_xcd_block((int)bb, (int)nblk2), (int)q2, (int)r2, set0n, cntn);
-            if (cntn > (int)rsc2) cntn = (int)rsc2;
-            for (int rs = 0; rs < cntn; ++rs) {
-                const uint8_t* const pset = pq + (size_t)(set0n + rs) * setb + (size_t)lane * 16u;
-                for (uint32_t sg = 0; sg < sps; ++sg) {
-                    const uint8_t* p = pset + (size_t)sg * segs;
-                    if (pps >= 4) {
-                        for (uint32_t pc = 0; pc < pps; pc += 4) v3_dma16_run<4>(p + (size_t)pc * 1024u, pad);
-                    } else if (pps == 2) {
-                        v3_dma16_run<2>(p, pad);
-                    } else {
-                        v3_dma16_run<1>(p, pad);
-                    }
-                    if (deep <= 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else if (deep <= 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (deep <= 32) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(55)" ::: "memory");       // (the counter holds 63; a segment is at most 8 pieces)
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                                               // step 5
-        return;
-    }
-#endif
 
     // ---- 1. staging by LDS-DMA.  x: the waves take pieces w, w + NW, ..; per row set the scale words (piece j = wave) and
     //         the outlier rows (the last 4 waves, one piece each).  No VGPR destination, no VALU on the data, nothing to
@@ -461,9 +360,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
     const int PX = XB >> 10, SPS = SZB >> 10;
     const int SRB = v3_szraw_bytes(G.ngroups), SPR = SRB >> 10;
     auto stage_all = [&]() {
-        if (ABL & 16) {
-            // lab: no staging at all (the results are garbage) -- what the whole staging prologue costs
-        } else if (XG) {
+        if (XG) {
             // x fragments come straight from global memory (step 4)
         } else if (!XN) {
             // (a gathering launch stages the rows as they are into xraw; step 3b writes xs)
@@ -481,7 +378,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                              __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)xg + ((uint32_t)(p - PF) << 10)));
             }
         }
-        if (!(ABL & 16)) {
+        {
     #pragma unroll
             for (int rs = 0; rs < RSC; ++rs) {
                 const int set = set_of(rs);
@@ -501,8 +398,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             }
         }
     };
-    // ABL & 256 (lab): the ring first, the staging pieces behind it (the staging wait then covers the ring's first loads too)
-    if (!(ABL & 256)) stage_all();
+    stage_all();
 
     // ---- 2. weight stream: ring of D loads per wave, branch-free, oldest first.  The wave's work is the sequence
     //         c = 0 .. nsw * RSC - 1 of (step wave + NW (c / RSC), row set c % RSC): STEP-major, so the x fragments and the bias
@@ -531,7 +427,6 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         __builtin_amdgcn_sched_barrier(0);
     });
 
-    if (ABL & 256) stage_all();
     asm volatile("" ::"s"(G.nsteps), "s"(ssq_n), "s"(ssq_in), "s"(residual), "s"(gamma_out), "s"(eps), "s"(bias), "s"(yout), "s"(y32),
                  "s"(ynorm), "s"(ssq_out), "s"(idsp));
     V3_STAMP(1);
@@ -543,7 +438,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // ---- 3. staged data complete: this wave's pieces are older than its D ring loads
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ABL & 256) ? 0 : D) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D) : "memory");
     // ---- 2b. epilogue-only operands, requested BEHIND the ring (they must not delay the weight stream): wave 1 the
     //          residual / gamma_out values of the block's rows, waves 2 and 3 the producer's partial sums of squares.  They
     //          complete before the vmcnt(0) every wave executes in front of the final barrier.
@@ -622,7 +517,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
 
     // fp16 outlier columns [K - 128, K): one MFMA step per row set, B fragments from the swizzled LDS rows; the wave whose
     // turn step `nfull` would be takes it, before its ring steps
-    if (OUTL && wave == (G.nfull & (NW - 1))) {
+    if (OUTL && wave == G.nfull % NW) {
         const v3h8* px = (const v3h8*)(xa + (size_t)G.nfull * 256);
         v3h8 xo[4];
 #pragma unroll
@@ -673,7 +568,6 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             for (int w = 0; w < 4; ++w) o[w] = px[w];
         };
         auto bias_sums = [&](const v3h8 (&x4)[4], val_t& lo, val_t& hi) {
-            if (ABL & 1) { lo = hi = v3_zero<MB>(); return; }
             f32x4 A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[0], c8, z4, 0, 0, 0);
             f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[1], c8, z4, 0, 0, 0);
             A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, A0, 0, 0, 0);
@@ -722,10 +616,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                                                 : *(const uint32_t*)(sp + (more_steps ? s_stride : 0u));
             val_t lo, hi;
             const ring_t wv = slot;
-            if (ABL & 4) {
-                lo = v3_zero<MB>() + __builtin_bit_cast(float, wv[0] ^ wv[1]);
-                hi = v3_zero<MB>() + __builtin_bit_cast(float, wv[2] ^ wv[BITS == 3 ? 0 : 3]);
-            } else {
+            {
                 // fragment j = pair j of every word w: k = 8j + 2w, +1 (w = 0..3) -- the 8 consecutive k of x slot j
                 u32x4 bf[4];
                 if (BITS == 4) {
@@ -768,7 +659,6 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                     hi = v3_pick<MB>(Phi);
                 }
             }
-            if (ABL & 4) fold(acc[prev_rs]);
             pv_lo = lo; pv_hi = hi; pv_alo = alo; pv_ahi = ahi; pv_szw = szw;
             szw = szw_n;
             issue(slot, std::integral_constant<int, (rs + D) % RSC>{});      // the slot's next load: number c + D of the sequence
@@ -816,10 +706,6 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         float sp_ = (b0 < ssq_n ? p0[0] : 0.f) + (b0 + 1 < ssq_n ? p0[1] : 0.f) + (b0 + 2 < ssq_n ? p0[2] : 0.f) + (b0 + 3 < ssq_n ? p0[3] : 0.f);
         sp_ = wave_sum(sp_);
         if (lane == 0) ssq_part[wave - 2] = sp_;
-    }
-    if constexpr ((ABL & 32) != 0 && MB == 1) {     // lab: no cross-wave sum, no barrier -- every wave stores its own partial (garbage results)
-        if (kc == 0 && wave == 0) yout[set0 * 16 + nl] = (f16)acc[0];
-        return;
     }
     if constexpr (MB == 1) {
         if (kc == 0)
@@ -880,23 +766,10 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             }
             const f16 g16 = (f16)gv, u16 = (f16)uv;
             const f16 r16 = (f16)(silu_f32((float)g16) * (float)u16);
-#if defined(QEFT_LAB)
-            if (ABL & 8) { asm volatile("" :: "v"(r16)); ts[6] = wall_clock64(); }
-#endif
+            V3_STAMP_VALUE(r16);
             yout[(set0 + rs) * 8 + n] = r16;
         }
-#if defined(QEFT_LAB)
-        if (ABL & 8) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (tid == 0) {
-                for (int i = 0; i < 4; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
-                a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5];
-                a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6];
-                a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
-                a.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15;      // HW_REG_XCC_ID
-            }
-        }
-#endif
+        V3_STAMP_FLUSH();
         return;
     }
     float sq = 0.f;
@@ -904,9 +777,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         const int row = set0 * 16 + tid;
         float v = row_sum(tid >> 4, tid & 15);
         if (bias) v += (float)bias[row];
-#if defined(QEFT_LAB)
-        if (ABL & 8) { asm volatile("" :: "v"(v)); ts[6] = wall_clock64(); }
-#endif
+        V3_STAMP_VALUE(v);
         if (residual) {
             v += ((const float*)epl)[tid];                          // lanes [0, 16) x 4 floats = the block's RS * 16 rows
             y32[row] = v;
@@ -922,18 +793,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         sq = wave_sum(sq);
         if (lane == 0) ssq_out[blockIdx.x] = sq;
     }
-#if defined(QEFT_LAB)
-    if (ABL & 8) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-            for (int i = 0; i < 4; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ts[i];
-            a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5];
-            a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6];
-            a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64();
-            a.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15;      // HW_REG_XCC_ID
-        }
-    }
-#endif
+        V3_STAMP_FLUSH();
 }
 #endif  // __HIPCC__
 

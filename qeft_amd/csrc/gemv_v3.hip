@@ -56,6 +56,11 @@ static bool gemv_v3_plan(V3Args& a, int& nw, size_t& smem) {
     // several blocks per CU (more than 256 blocks): 4-wave blocks, one wave per SIMD each
     nw = f_nw == 4 || f_nw == 8 ? f_nw : (nblk > 256 && a.m <= 1 ? 4 : V3_NW);
     if (a.m > 1) nw = V3_NW;
+    // one row set per block and many steps per wave (down_proj: K = 11008, 85 full steps): 12 waves share the steps 8 / 7 instead of
+    // 11 / 10: down_proj 7.42 -> 7.33 us (profiles/r04_gemv_lab.txt; the same file holds the correction sums tabulated up front per
+    // wave instead of 4 MFMAs per step: +0.4 us on o_proj, +1.0 us on down_proj, not adopted); QEFT_GEMV_NW12=0 keeps 8 (A/B)
+    static const int no_nw12 = getenv("QEFT_GEMV_NW12") && atoi(getenv("QEFT_GEMV_NW12")) == 0;
+    if (!no_nw12 && !f_nw && a.m <= 1 && nblk <= 256 && a.rs_cap == 1 && a.g.nfull >= 64) nw = 12;
     a.nw = nw;
     smem = v3_lds(a.g.K, a.g.ngroups, a.g.n_out, a.rs_cap, a.m, nw, a.xn_gamma != nullptr && a.szp != nullptr, a.szp == nullptr, a.ids != nullptr, a.xg).total;
     return smem <= 160 * 1024 && nblk < 65536;       // (nblk, sets_r share dwords with rs_cap, sets_q)
@@ -127,7 +132,7 @@ long long gemv_v3_count_out_of_range(const V3Geom& G, int n_rows_have, int n_ssq
                     for (int j = 0; j < 4; ++j) bad += v3_ow_off(set0 + rs, j, lane) + 16 > ow_bytes;
                 if (kc == 0) bad += (set0 + rs) * 16 + nl >= n_rows_have;
             }
-            for (int NW = 4; NW <= 16; NW *= 2)        // every wave count the kernel is (or was) instantiated with
+            for (int NW : {4, 8, 12, 16})               // every wave count the kernel is (or was) instantiated with
                 for (int wave = 0; wave < NW; ++wave) {
                     const int nsw = (G.nfull - wave + NW - 1) / NW;
                     const uint32_t stepb = bits == 3 ? 768u : 256u, last = bits == 3 ? v3w3_last_step_off(G) : v3_last_step_off(G);
@@ -162,7 +167,7 @@ long long gemv_v3_count_out_of_range_ckpt(const V3Geom& G, int n_rows_have, int 
             const int nl = lane & 15, kc = lane >> 4, row = nl < m - 1 ? nl : m - 1;
             for (int step = 0; step < G.nsteps; ++step) bad += (size_t)row * G.K * 2 + (size_t)step * 256 + kc * 64 + 64 > x_bytes;
         }
-    for (int nw = 4; nw <= 16; nw *= 2) {
+    for (int nw : {4, 8, 12, 16}) {
         const V3Lds L = v3_lds(G.K, G.ngroups, G.n_out, rs_cap, m, nw, false, true, gather);
         if (L.total > 160 * 1024) continue;     // not launched (gemv_v3_plan)
         for (int b = 0; b < nblk; ++b) {

@@ -1,6 +1,6 @@
 // Lab harness for the v3 decode GEMV (GPU box only): times kernel variants directly, cycling 12 weight sets per kind so that
 // nothing is served from L2 / MALL, on the four launch kinds of a Llama-2-7B decoder layer.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DQEFT_LAB -mllvm -amdgpu-kernarg-preload-count=16 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o /tmp/gemv_v3_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 -I qeft_amd/csrc tools/gemv_v3_lab.hip -o build/gemv_v3_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +9,14 @@
 #include <string>
 #include <functional>
 #include <algorithm>
+// lab hooks of gemv_v3.h: time stamps of wave 0 of every block when the launch carries a dbg buffer
+#define V3_STAMP_DECL long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+#define V3_STAMP(i) do { if (a.dbg) ts[i] = wall_clock64(); } while (0)
+#define V3_STAMP_VALUE(v) do { if (a.dbg) { asm volatile("" ::"v"(v)); ts[6] = wall_clock64(); } } while (0)
+#define V3_STAMP_FLUSH() do { if (a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) { \
+    for (int i_ = 0; i_ < 4; ++i_) a.dbg[(size_t)blockIdx.x * 8 + i_] = ts[i_]; \
+    a.dbg[(size_t)blockIdx.x * 8 + 5] = ts[5]; a.dbg[(size_t)blockIdx.x * 8 + 6] = ts[6]; a.dbg[(size_t)blockIdx.x * 8 + 4] = wall_clock64(); \
+    a.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(6164) & 15; } } } while (0)
 #include "gemv_v3.h"
 
 namespace qeft { thread_local const char* g_last_variant = ""; }
@@ -68,46 +76,26 @@ static int qeft_lab_blocks(int nsets) {     // gemv_v3_blocks (gemv_v3.hip)
     return nblk;
 }
 struct Kind { const char* name; int n, k, mode; bool ssq, res; };
-// the next launch's ring head (gemv_v3_prefetch_plan of gemv_v3.hip, with the lab's own geometry)
-static V3Prefetch lab_pf(const void* qw, int n, int k, int nblk, int nw, int D, int mult, int pace) {
-    V3Prefetch p{};
-    const int nsets = n / 16, rsc = (nsets + nblk - 1) / nblk, nfull = (k - 128) / 128;
-    int head = nw * ((D + rsc - 1) / rsc) * mult;
-    if (head > nfull) head = nfull;
-    int lg = 0;
-    while ((1 << lg) < (head + 3) / 4 && (2 << lg) <= k / 512) ++lg;
-    p.qw = (const uint8_t*)qw;
-    p.set_bytes = (uint32_t)k * 8u;
-    p.seg_stride = (uint32_t)k * 2u;
-    p.geom = (uint32_t)nblk | ((uint32_t)rsc << 16) | ((uint32_t)lg << 20) | (2u << 24);
-    p.sets = (uint32_t)(nsets / nblk) | ((uint32_t)(nsets % nblk) << 16);
-    p.stride = (nblk & ~7) ? (uint32_t)(nblk & ~7) : (1u << 30);
-    p.pace = (uint32_t)pace;
-    return p;
-}
 struct Case { std::string label; double bytes; int L; std::function<void(int)> f; std::vector<float> us; };
 static std::vector<Case> g_cases;
 struct Bufs { void *qw, *szp, *ow; };
 
-template <int NW, int D, int MODE, int ABL, int RSC>
+template <int NW, int D, int MODE, int RSC, bool TAB = false>
 static void launch_r(const V3Args& a, int nblk, size_t smem) {
-    auto kern = gemv_v3_kernel<NW, D, true, MODE, ABL, 4, 1, RSC>;
+    auto kern = gemv_v3_kernel<NW, D, true, MODE, 4, 1, RSC>;      // (TAB: round 4's tabulated correction sums, measured and removed from gemv_v3.h: profiles/r04_gemv_lab.txt)
     if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64 + (a.pf.qw ? 64 : 0)), smem, 0, V3_KERNEL_ARGS(a));
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(NW * 64), smem, 0, V3_KERNEL_ARGS(a));
 }
 // the lab's four launch kinds have 3 (q|k|v, gate|up) or 1 (o_proj, down_proj) row sets per block under the product's block rule
-template <int NW, int D, int MODE, int ABL>
+template <int NW, int D, int MODE, bool TAB = false>
 static void launch(const V3Args& a, int nblk, size_t smem) {
-    if (a.rs_cap == 3) launch_r<NW, D, MODE, ABL, 3>(a, nblk, smem);
-    else if (a.rs_cap == 1) launch_r<NW, D, MODE, ABL, 1>(a, nblk, smem);
+    if (a.rs_cap == 3) launch_r<NW, D, MODE, 3>(a, nblk, smem);
+    else if (a.rs_cap == 1) launch_r<NW, D, MODE, 1, TAB && MODE == V3_MODE_PLAIN>(a, nblk, smem);
     else { printf("    (rs_cap %d not instantiated in the lab)\n", a.rs_cap); }
 }
 
-template <int NW, int D, int ABL>
-static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk, int pfmult = 0, int pace = 8) {
+static V3Args make_args(const Kind& kd, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk, int nw) {
     const int nsets = kd.n / 16;
-    if (nblk > nsets) nblk = nsets;
-    if ((nsets + nblk - 1) / nblk > V3_MAX_RS) { printf("    (skip: %d blocks need > %d sets per block)\n", nblk, V3_MAX_RS); return; }
     V3Args a{};
     a.x = (const f16*)x;
     a.g = V3Geom{kd.k, 128, kd.k / 128, (kd.k - 128) / 128, kd.k / 128, nsets};
@@ -115,18 +103,26 @@ static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h3
     a.ssq_in = kd.ssq ? (const float*)ssq : nullptr; a.n_ssq_in = kd.ssq ? 256 : 0; a.eps = 1e-5f;
     a.residual = kd.res ? (const float*)h32 : nullptr; a.y32 = kd.res ? (float*)h32 : nullptr;
     a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
-    a.y = (f16*)y;
-    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
-    auto f = [a, &B, &kd, nblk, smem, pfmult, pace](int l) {
-        V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
-        if (pfmult > 0) b.pf = lab_pf(B[(l + 1) % B.size()].qw, kd.n, kd.k, nblk, NW, D, pfmult, pace);     // the next launch of the cycle
-        if (kd.mode == V3_MODE_PAIR) { if constexpr (NW <= 8) launch<NW, D, V3_MODE_PAIR, ABL>(b, nblk, smem); }
-        else launch<NW, D, V3_MODE_PLAIN, ABL>(b, nblk, smem);
-    };
+    a.y = (f16*)y; a.nw = nw;
+    return a;
+}
+
+template <int NW, int D, bool TAB = false>
+static void run(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk) {
+    const int nsets = kd.n / 16;
+    if (nblk > nsets) nblk = nsets;
+    if ((nsets + nblk - 1) / nblk > V3_MAX_RS) { printf("    (skip: %d blocks need > %d sets per block)\n", nblk, V3_MAX_RS); return; }
     if (kd.mode == V3_MODE_PAIR && NW > 8) return;
+    const V3Args a = make_args(kd, x, y, h32, gam, ssq, ynorm, nblk, NW);
+    const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
+    auto f = [a, &B, &kd, nblk, smem](int l) {
+        V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
+        if (kd.mode == V3_MODE_PAIR) { if constexpr (NW <= 8) launch<NW, D, V3_MODE_PAIR>(b, nblk, smem); }
+        else launch<NW, D, V3_MODE_PLAIN, TAB>(b, nblk, smem);
+    };
     const double bytes = (double)kd.n * (kd.k - 128) / 2 + 2.0 * (kd.k / 128) * kd.n * 2 + (double)kd.n * 128 * 2 + 2 * kd.k + 2 * kd.n;
     char label[96];
-    snprintf(label, sizeof label, "%-4s NW=%2d D=%d blocks=%4d ABL=%2d warm=%d pace=%4d", kd.name, NW, D, nblk, ABL, pfmult, pace);
+    snprintf(label, sizeof label, "%-4s NW=%2d D=%d blocks=%4d%s", kd.name, NW, D, nblk, TAB ? " TAB" : "    ");
     g_cases.push_back(Case{label, bytes, (int)B.size(), f, {}});
 }
 // every registered case timed `rounds` times, the cases interleaved (box-level drift hits all of them alike); min and median
@@ -142,18 +138,10 @@ static void measure_cases(int rounds) {
     g_cases.clear();
 }
 
-// ABL = 8: time stamps of wave 0 of every block (100 MHz ticks) -> where a launch's time goes
-template <int NW, int D, int ABLX = 0>
-static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk, int pfmult = 0, int pace = 8) {
-    const int nsets = kd.n / 16;
-    V3Args a{};
-    a.x = (const f16*)x;
-    a.g = V3Geom{kd.k, 128, kd.k / 128, (kd.k - 128) / 128, kd.k / 128, nsets};
-    a.rs_cap = (nsets + nblk - 1) / nblk; a.nblk = nblk; a.sets_q = nsets / nblk; a.sets_r = nsets % nblk;
-    a.ssq_in = kd.ssq ? (const float*)ssq : nullptr; a.n_ssq_in = kd.ssq ? 256 : 0; a.eps = 1e-5f;
-    a.residual = kd.res ? (const float*)h32 : nullptr; a.y32 = kd.res ? (float*)h32 : nullptr;
-    a.gamma_out = kd.res ? (const f16*)gam : nullptr; a.ynorm = (f16*)ynorm; a.ssq_out = (float*)ssq + 512;
-    a.y = (f16*)y;
+// time stamps of wave 0 of every block (100 MHz ticks) -> where a launch's time goes
+template <int NW, int D>
+static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, void* h32, void* gam, void* ssq, void* ynorm, int nblk) {
+    const V3Args a = make_args(kd, x, y, h32, gam, ssq, ynorm, nblk, NW);
     long long* dbg; CK(hipMalloc(&dbg, (size_t)nblk * 64 * 6));
     const size_t smem = v3_smem_bytes(kd.k, kd.k / 128, 128, a.rs_cap, false, 1, NW);
     std::vector<long long> h((size_t)nblk * 8 * 6);
@@ -162,15 +150,14 @@ static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, voi
         for (int l = 0; l < 6; ++l) {
             V3Args b = a; b.qw = (const uint8_t*)B[l].qw; b.szp = (const uint8_t*)B[l].szp; b.ow = (const uint8_t*)B[l].ow;
             b.dbg = dbg + (size_t)l * nblk * 8;
-            if (pfmult > 0) b.pf = lab_pf(B[(l + 1) % 6].qw, kd.n, kd.k, nblk, NW, D, pfmult, pace);
             if (l == 0 && warm == 2) CK(hipEventRecord(e0, 0));
-            if (kd.mode == V3_MODE_PAIR) launch<NW, D, V3_MODE_PAIR, 8 | ABLX>(b, nblk, smem); else launch<NW, D, V3_MODE_PLAIN, 8 | ABLX>(b, nblk, smem);
+            if (kd.mode == V3_MODE_PAIR) { if constexpr (NW <= 8) launch<NW, D, V3_MODE_PAIR>(b, nblk, smem); } else launch<NW, D, V3_MODE_PLAIN>(b, nblk, smem);
         }
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    printf("  %-4s NW=%2d D=%d blocks=%4d ABL=%d warm=%d pace=%d: %.2f us per launch (6 back to back); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, ABLX, pfmult, pace, ms * 1e3 / 6);
+    printf("  %-4s NW=%2d D=%d blocks=%4d: %.2f us per launch (6 back to back, stamped); per launch, us after the first block's entry (min..max over blocks):\n", kd.name, NW, D, nblk, ms * 1e3 / 6);
     long long prev_end = 0;
     for (int l = 0; l < 6; ++l) {
         long long t0 = 1LL << 62, mx[7] = {0, 0, 0, 0, 0, 0, 0}, mn[7];
@@ -182,14 +169,12 @@ static void timeline(const Kind& kd, std::vector<Bufs>& B, void* x, void* y, voi
             for (int i = 0; i < 7; ++i) { if (p[i] < mn[i]) mn[i] = p[i]; if (p[i] > mx[i]) mx[i] = p[i]; }
             tail[0] += (p[5] - p[3]) / 100.0 / nblk; tail[1] += (p[6] - p[5]) / 100.0 / nblk; tail[2] += (p[4] - p[6]) / 100.0 / nblk;
         }
-        printf("     launch %d: entry 0..%.2f | ring issued %.2f..%.2f | staging landed %.2f..%.2f | steps done %.2f..%.2f | end %.2f..%.2f", l,
-               (mx[0] - t0) / 100.0, (mn[1] - t0) / 100.0, (mx[1] - t0) / 100.0, (mn[2] - t0) / 100.0, (mx[2] - t0) / 100.0,
-               (mn[3] - t0) / 100.0, (mx[3] - t0) / 100.0, (mn[4] - t0) / 100.0, (mx[4] - t0) / 100.0);
-        printf(" | tail per block: wait for the block's waves %.2f, epilogue math %.2f, store + ack %.2f", tail[0], tail[1], tail[2]);
-        if (l) printf(" | gap since previous end %.2f", (t0 - prev_end) / 100.0);
-        printf(" | XCD of blocks 0..9:");
-        for (int b = 0; b < 10 && b < nblk; ++b) printf(" %lld", h[((size_t)l * nblk + b) * 8 + 7]);
-        printf("\n");
+        if (l == 3) {
+            printf("     launch %d: entry 0..%.2f | ring issued %.2f..%.2f | staging landed %.2f..%.2f | steps done %.2f..%.2f | end %.2f..%.2f", l,
+                   (mx[0] - t0) / 100.0, (mn[1] - t0) / 100.0, (mx[1] - t0) / 100.0, (mn[2] - t0) / 100.0, (mx[2] - t0) / 100.0,
+                   (mn[3] - t0) / 100.0, (mx[3] - t0) / 100.0, (mn[4] - t0) / 100.0, (mx[4] - t0) / 100.0);
+            printf(" | tail per block: wait for the block's waves %.2f, epilogue math %.2f, store + ack %.2f | gap since previous end %.2f\n", tail[0], tail[1], tail[2], (t0 - prev_end) / 100.0);
+        }
         prev_end = mx[4];
     }
     CK(hipFree(dbg));
@@ -235,59 +220,15 @@ int main() {
         printf("%s: n=%d k=%d\n", kd.name, kd.n, kd.k);
         const int nsets = kd.n / 16;
         const int nb = (splitk && kd.n == 8192) ? 512 : qeft_lab_blocks(nsets);
-        if (getenv("LAB_RF")) {       // ring first (ABL & 256): the weight ring issued in front of the staging pieces
-            auto rf_cases = [&](auto nwtag, auto dtag) {
-                constexpr int NWc = decltype(nwtag)::value, D = decltype(dtag)::value;
-                run<NWc, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-                run<NWc, D, 256>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-                measure_cases(9);
-                timeline<NWc, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-                timeline<NWc, D, 256>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-            };
-            if (kd.mode == V3_MODE_PAIR) rf_cases(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
-            else if (kd.n == 12288) rf_cases(std::integral_constant<int, 8>{}, std::integral_constant<int, 6>{});
-            else if (kd.k == 4096) rf_cases(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
-            else rf_cases(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{});
-            for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
-            (void)hipFree(x); (void)hipFree(y);
-            continue;
-        }
-        if (getenv("LAB_PF")) {       // the cross-launch L2 warm-up (gemv_v3.h step 0): off / on at 8, 4, 2 pieces in flight / started later / twice the head
-            auto pf_cases = [&](auto dtag) {
-                constexpr int D = decltype(dtag)::value;
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 0);
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 8);
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 16);
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 32);
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 64);
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 64 | (2 << 8));
-                run<8, D, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 2, 64);
-                measure_cases(7);
-                timeline<8, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 0);
-                timeline<8, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 64);
-                timeline<8, D>(kd, B, x, y, h32, gam, ssq, ynorm, nb, 1, 16);
-            };
-            if (kd.mode == V3_MODE_PAIR) printf("  (skipped)\n");
-            else if (kd.n == 12288) pf_cases(std::integral_constant<int, 6>{});
-            else if (kd.k == 4096) pf_cases(std::integral_constant<int, 2>{});
-            else pf_cases(std::integral_constant<int, 4>{});
-            for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
-            (void)hipFree(x); (void)hipFree(y);
-            continue;
-        }
-        run<8, 2, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        run<8, 4, 16>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-        if (getenv("LAB_NW4")) {
-            run<4, 4, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-            run<4, 6, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
-            run<4, 8, 0>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        run<8, 6>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+        if (kd.mode != V3_MODE_PAIR && !kd.ssq) {      // one row set per block: step balance (K = 11008: 85 full steps) and tabulated correction sums
+            run<12, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
+            run<12, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         }
         measure_cases(7);
         if (full) {
-            timeline<8, 2>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
             timeline<8, 4>(kd, B, x, y, h32, gam, ssq, ynorm, nb);
         }
         for (auto& b : B) { (void)hipFree(b.qw); (void)hipFree(b.szp); (void)hipFree(b.ow); }
