@@ -363,9 +363,9 @@ def boundary_gemv_records(dev, sets=8, reps=20):
                     "bytes = algorithmic bytes of the call (SURVEY 8d) with m rows of x and y"}
 
 
-def mid_m_records(dev, ms=(16, 64, 512, 1024), layers=4, reps=25):
+def mid_m_records(dev, ms=(16, 32, 64, 512, 1024), layers=4, reps=25):
     """prefill_mid_m: the forward GEMM below the M = 2048 tier -- M = 16 (a batch of 16 decoding sequences: the rows ride on the
-    decode GEMV), 64 (benchmark.py's 64-token prompt), 512 and 1024 (short prompts, fine-tune batches) on the three 7B shapes;
+    decode GEMV), 32 and 64 (benchmark.py's 64-token prompt: the weight-stationary tier gemm_ws.hip), 512 and 1024 (short prompts, fine-tune batches) on the three 7B shapes;
     us, TFLOP/s, fraction of the dense fp16 MFMA peak, variant."""
     import torch
     from qeft_amd import _lib, qeft_cuda

@@ -52,6 +52,9 @@ hipError_t pack_oweight_launch(const void* ow, void* il, int N, int R, hipStream
 hipError_t pack_scales_launch(const void* scales, const void* zeros, void* out, int N, int ngroups, hipStream_t st);
 extern const void* const kSiluPair64;
 bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out);
+bool gemm_ws_supported(int m, int n, int k, int group_size, int n_out);                                  // gemm_ws.hip
+hipError_t gemm_ws_launch(const void* x, const void* qweight, const void* scales, const void* zeros, const void* oweight, const void* bias,
+                          void* y, int m, int n, int k, int n_out, hipStream_t st);
 hipError_t gemm_w4_launch(const void* x, const void* qw, const void* scales, const void* zeros, const void* ow,
                           const void* bias, void* y, int M, int N, int K, int G, int n_out, hipStream_t st,
                           void* workspace = nullptr, size_t workspace_bytes = 0, const void* silu_gate = nullptr,
@@ -92,6 +95,12 @@ static int finish(hipError_t e) {
 // QEFT_GEMV_V3=0: the reference's gemv entries keep the round-1 kernels (A/B timing, and the parity tests of those kernels)
 static bool v3_route_enabled() {
     static const int on = [] { const char* e = getenv("QEFT_GEMV_V3"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
+// QEFT_GEMM_WS=0: 17 .. 64 rows keep the round-3 routes (split-K GEMM tiles / the round-1 small-M GEMV) (A/B timing)
+static bool ws_route_enabled() {
+    static const int on = [] { const char* e = getenv("QEFT_GEMM_WS"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
 
@@ -281,6 +290,11 @@ static int gemm_impl(const void* x, const void* qweight, const void* scales, con
                                           ? kGemmRowsOnGemvLaunches : (1 << 30));      // (per-channel scales: no split-K tier to fall to)
         if (r != V3_NOT_TAKEN) return r;
     }
+    if (ws_route_enabled() && (n_out > 0) == (oweight != nullptr) && aligned16(scales) && aligned16(scaled_zeros) &&
+        qeft::gemm_ws_supported(m, n, k, group_size, n_out)) {
+        // 17 .. 64 rows: the weight-stationary tier (gemm_ws.hip) -- one launch, one pass over the packed weights, no workspace
+        return finish(qeft::gemm_ws_launch(x, qweight, scales, scaled_zeros, oweight, bias, y, m, n, k, n_out, (hipStream_t)stream));
+    }
     if (small_m_route(m, n, workspace != nullptr && workspace_bytes > 0) && (n_out > 0) == (oweight != nullptr) &&
         !(m <= qeft::V3_MAX_M && v3_route_enabled() && n % 16 == 0 && qeft::gemv_v3_ok(k, group_size, n_out))) {
         // few rows: stream the weights once per 16 rows through the MFMA GEMV instead of 128-row GEMM tiles.
@@ -382,6 +396,8 @@ long long qeft_gemm_w4_workspace_bytes(int m, int n, int k, int n_out) {
         // will put them there, the split-K tier's otherwise (three weight streams would cost more than its partial sums)
         const int l = v3_rows_launches(m, n, k, 128, n_out);
         if (l >= 1 && l <= kGemmRowsOnGemvLaunches) return 0;
+    } else if (ws_route_enabled() && qeft::gemm_ws_supported(m, n, k, 128, n_out)) {
+        return 0;       // (group size 128 assumed, as above: the weight-stationary tier needs no workspace)
     } else if (small_m_route(m, n, true)) {
         return 0;
     }

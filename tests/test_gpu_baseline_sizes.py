@@ -128,6 +128,62 @@ def test_gemm_entry_8_to_16_rows_on_the_decode_gemv(n, k, m):
         assert elem_err_ok(y0.cpu().numpy(), ref0)
 
 
+@pytest.mark.parametrize("n,k", [(4096, 4096), (11008, 4096), (4096, 11008), (5120, 5120), (13824, 5120)])
+@pytest.mark.parametrize("m", [17, 24, 33, 48, 64])
+def test_gemm_entry_17_to_64_rows_weight_stationary(n, k, m):
+    """17 .. 64 rows at the GEMM entries (benchmark.py:118's 64-token prompt; the reference's M <= 32 / M <= 64 tiers,
+    gemm_cuda.cu:952-978): ONE launch of the weight-stationary kernel (gemm_ws.hip) -- every output vs the oracle, element-wise,
+    with and without a split-K workspace in reach, and the variant asserted."""
+    from qeft_amd import _lib, qeft_cuda
+    bufs = O.make_layer(n, k, R, G, seed=n + k + m, bias=True)
+    t = layer_to_torch(bufs, DEV)
+    x = O.make_activation(m, k, R, seed=m)
+    y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"], t["bias"])
+    variant = _lib.last_variant()
+    torch.cuda.synchronize()
+    assert variant == "gemm_ws", (variant, n, k, m)
+    yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"], bufs["bias"], G).astype(np.float64)
+    got = y.cpu().numpy()
+    assert got.shape == (m, n)
+    assert rel_err(got, yref) < REL_TOL
+    assert elem_err_ok(got, yref), (variant, n, k, m)
+    # the plain C entry without a workspace (ADVICE r3: no test covered m = 17 .. 64 there) reaches the same kernel
+    lib = _lib.lib()
+    y2 = torch.empty(m, n, dtype=torch.float16, device=DEV)
+    xt = torch.from_numpy(x).to(DEV)
+    _lib.check(lib.qeft_gemm_w4(xt.data_ptr(), t["qweight"].data_ptr(), t["scales"].data_ptr(), t["scaled_zeros"].data_ptr(),
+                                t["oweight"].data_ptr(), t["bias"].data_ptr(), y2.data_ptr(), m, n, k, G, R,
+                                torch.cuda.current_stream().cuda_stream))
+    assert _lib.last_variant() == "gemm_ws"
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
+    if n == 4096 and k == 4096:
+        # no outlier slice: gemm_4bit's own semantics (every column from the nibbles)
+        b0 = O.make_layer(n, k, 0, G, seed=5)
+        t0 = layer_to_torch(b0, DEV)
+        y0 = qeft_cuda.gemm_4bit(xt, t0["qweight"], t0["scales"], t0["scaled_zeros"])
+        assert _lib.last_variant() == "gemm_ws"
+        ref0 = O.quant_linear(x, b0["qweight"], b0["scales"], b0["scaled_zeros"], None, None, G).astype(np.float64)
+        assert elem_err_ok(y0.cpu().numpy(), ref0)
+
+
+def test_weight_stationary_tier_ragged_and_small_shapes():
+    """Row-set counts that do not divide over the blocks (short blocks repeat their last set), a single row set, K = 256 (one full
+    step + the outlier step: most waves have no step at all), n_out = 0 with K = 128 k."""
+    from qeft_amd import _lib, qeft_cuda
+    for (n, k, r, m) in [(16, 256, R, 17), (48, 384, R, 40), (4112, 1024, R, 64), (1040 * 16, 512, R, 33), (272, 1152, 0, 25), (8208, 2048, R, 64)]:
+        bufs = O.make_layer(n, k, r, G, seed=n + k + m)
+        t = layer_to_torch(bufs, DEV)
+        x = O.make_activation(m, k, max(r, 1), seed=m)
+        y = qeft_cuda.gemm_4bit_qeft(torch.from_numpy(x).to(DEV), t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"] if r else None)
+        assert _lib.last_variant() == "gemm_ws", (_lib.last_variant(), n, k, r, m)
+        torch.cuda.synchronize()
+        yref = O.quant_linear(x, bufs["qweight"], bufs["scales"], bufs["scaled_zeros"], bufs["oweight"] if r else None, None, G).astype(np.float64)
+        got = y.cpu().numpy()
+        assert rel_err(got, yref) < REL_TOL, (n, k, r, m)
+        assert elem_err_ok(got, yref), (n, k, r, m)
+
+
 def test_variant_names_follow_the_routing():
     """The routing tiers below the BASELINE sizes keep their own names (and their own tests in test_gpu_gemm.py)."""
     from qeft_amd import _lib, qeft_cuda
