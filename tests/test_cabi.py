@@ -148,12 +148,15 @@ def test_round2_entries_reject_bad_arguments_without_a_gpu():
 
 def test_gemm_workspace_follows_the_row_routing(lib):
     """No compute: the split-K workspace the shim asks for matches where gemm_impl will send the rows -- up to 16 rows of a shape
-    the decode GEMV serves ride on it (no workspace), from 17 rows on the split-K tier wants its partial-sum buffer, enough tiles
-    need none."""
+    the decode GEMV serves ride on it (no workspace), 17 .. 64 rows take the weight-stationary tier (gemm_ws.hip, one launch, no
+    workspace), from 65 rows on the split-K tier wants its partial-sum buffer, enough tiles need none."""
     f = lib.qeft_gemm_w4_workspace_bytes
     for (n, k) in ((4096, 4096), (11008, 4096), (4096, 11008), (13824, 5120)):
         for m in (8, 12, 16):
             assert f(m, n, k, 128) == 0, (m, n, k)                # gemv_v3_mb / gemv_v3_mb_xg
-        assert f(24, n, k, 128) >= 2 * 24 * n * 4, (n, k)           # split-K partial sums
+        for m in (17, 24, 64):
+            assert f(m, n, k, 128) == 0, (m, n, k)                # gemm_ws
+        assert f(96, n, k, 128) >= 2 * 96 * n * 4, (n, k)           # split-K partial sums
+    assert f(24, 4096, 4160, 128) >= 2 * 24 * 4096 * 4              # K % 128 != 0: not a shape the weight-stationary tier takes
     assert f(4096, 4096, 4096, 128) == 0
     assert f(16, 4096, 4160, 128) == 0                              # K % 128 != 0: the round-1 small-M route, no workspace either
