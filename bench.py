@@ -63,6 +63,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the PMC child run that fills roofline.traffic")
+    ap.add_argument("--collective", choices=("auto", "rccl", "oneshot"), default="auto",
+                    help="N > 1: the layer's all-reduce -- RCCL, the one-shot IPC kernel (qeft_amd/oneshot.py), or auto = one-shot if it "
+                         "passes its self-check on every rank, else RCCL")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the PMC child: two tokens' GEMV launches, no timing
     ap.add_argument("--no-per-kind", action="store_true", help="skip the per-launch-kind timing graphs")
     ap.add_argument("--no-extras", action="store_true",
@@ -485,7 +488,10 @@ def main():
         shape = model.shape
     else:
         model = QuantLlama(shape, dev, seed=0, fast_init=True)
-    eng = DecodeEngine(model, use_graph=not (args.no_graph or shared), tp_group=group)
+    eng = DecodeEngine(model, use_graph=not (args.no_graph or shared), tp_group=group,
+                       collective=args.collective if group is not None else "rccl")
+    if shared and not args.no_graph and eng.collective == "oneshot":
+        eng.use_graph = True        # the rehearsal's gloo collectives cannot be captured; the one-shot kernel can
     eng.greedy = True
     torch.cuda.synchronize(dev)
     t_build = time.time() - t_build
@@ -648,6 +654,34 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             multi["collective_us"] = {"all_reduce_fp32_bytes": shape.hidden * 4, "us": round(float(tt.item()), 2), "how": how,
                                       "per_token": 2 * shape.n_layers if getattr(eng, "tp3", False) else 4 * shape.n_layers}
+            multi["collective"] = eng.collective                    # what the timed tokens used
+            if eng.collective_note:
+                multi["collective_note"] = eng.collective_note      # why "auto" fell back to the group's collective
+            if eng.oneshot is not None:
+                # the one-shot kernel alone, the same way (64 dependent calls per replay)
+                b2 = torch.zeros(shape.hidden, dtype=torch.float32, device=dev)
+
+                def coll1():
+                    for _ in range(n_coll):
+                        eng.oneshot.all_reduce(b2)
+                coll1()
+                torch.cuda.synchronize(dev)
+                run1, how1 = coll1, "eager"
+                try:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1):
+                        coll1()
+                    run1, how1 = g1.replay, "hipgraph"
+                except Exception as e:
+                    multi["oneshot_capture_error"] = f"{type(e).__name__}: {e}"[:200]
+                    torch.cuda.synchronize(dev)
+                barrier()
+                t1 = _event_time_us(run1, 10, dev, warm_ms=5.0) / n_coll
+                tt1 = torch.tensor([t1], dtype=torch.float64, device=dev if not shared else "cpu")
+                dist.all_reduce(tt1, op=dist.ReduceOp.MAX)
+                eng.oneshot.check_status()
+                multi["collective_us"]["oneshot_us"] = round(float(tt1.item()), 2)
+                multi["collective_us"]["oneshot_how"] = how1
             per_rank = [None] * world
             dist.all_gather_object(per_rank, {"rank": rank, "gemv_GB/s": roof["achieved"] if roof else None,
                                               "gemv_frac": roof["frac"] if roof else None,
@@ -764,10 +798,10 @@ def main():
                                    f"{args.warmup} warm-up tokens before the timed region)",
                        "layers": shape.n_layers, "hipgraph": graph_ok,
                        "parallelism": ((f"tp{world}: q/k/v/gate/up row-sharded, o/down column-sharded + one all-reduce each "
-                                        f"(2 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})")
+                                        f"(2 collectives per layer{', shared-GPU rehearsal' if shared else ''})")
                                        if tp3 else
                                        (f"tp{world}: every linear row-sharded, one all-gather each "
-                                        f"(4 collectives per layer{', shared-GPU gloo rehearsal' if shared else ''})"))
+                                        f"(4 collectives per layer{', shared-GPU rehearsal' if shared else ''})"))
                        if group is not None else "single GPU",
                        "build_s": round(t_build, 1), "last_token": last_tok},
         }

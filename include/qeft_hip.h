@@ -323,6 +323,28 @@ int qeft_token_begin(const void* embed, const void* tok, const void* rope_tab, c
                      int hidden, int vocab, int max_seq, qeft_stream_t stream);
 int qeft_token_end(const void* logits, void* tok, int* pos, int vocab, int greedy, qeft_stream_t stream);
 
+/* One-shot all-reduce of the tensor-parallel decode path (csrc/oneshot.hip; no reference counterpart --
+ * the reference places whole layers on GPUs, qeft/utils/modelutils.py:21-57).  In-place fp32 sum of t[n] over `world` ranks
+ * (one process per GPU) by ONE kernel per rank: every rank writes its partial as 8-byte {value, tag} granules into slot `rank`
+ * of every rank's MAILBOX (device memory of the owning rank, mapped into the peers through hipIpcMemHandle: the export / open /
+ * close wrappers below), polls its own mailbox and sums the slots in rank order -- bit-identical on every rank.
+ *   boxes:  HOST array of `world` device pointers, box[r] = rank r's mailbox as mapped in THIS process (box[rank] = the local
+ *           allocation from qeft_oneshot_mailbox_alloc); each qeft_oneshot_mailbox_bytes(world, n) bytes, zeroed once;
+ *   seq:    one zeroed uint32 in device memory (the call counter: every rank must make the same sequence of calls);
+ *   status: two zeroed uint32 in device memory; status[0] != 0 after a call = a wait gave up (a peer never wrote).
+ * hipGraph-capturable (no host state changes per call); world <= qeft_oneshot_max_world(). */
+long long qeft_oneshot_mailbox_bytes(int world, int n);
+int qeft_oneshot_max_world(void);
+/* set-up helpers -- the ONLY entry points that allocate / synchronise: the mailbox is a zeroed hipMalloc block of its own (an
+ * IPC handle exports the whole allocation its pointer lives in; a caching allocator's sub-block would arrive at an unknown offset) */
+int qeft_oneshot_mailbox_alloc(int world, int n, void** dev_ptr_out);
+int qeft_oneshot_mailbox_free(void* dev_ptr);
+int qeft_oneshot_ipc_export(void* dev_ptr, void* handle_out /* 64 bytes, host */);
+int qeft_oneshot_ipc_open(const void* handle /* 64 bytes, host */, void** dev_ptr_out);
+int qeft_oneshot_ipc_close(void* dev_ptr);
+int qeft_oneshot_allreduce_f32(void* t, int n, void* const* boxes, int rank, int world, void* seq, void* status,
+                               qeft_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,14 @@ SIGNATURES = {
     "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_single_query_attention_alibi": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "qeft_oneshot_mailbox_bytes": [_i, _i],
+    "qeft_oneshot_max_world": [],
+    "qeft_oneshot_mailbox_alloc": [_i, _i, ctypes.POINTER(ctypes.c_void_p)],
+    "qeft_oneshot_mailbox_free": [_p],
+    "qeft_oneshot_ipc_export": [_p, _p],
+    "qeft_oneshot_ipc_open": [_p, ctypes.POINTER(ctypes.c_void_p)],
+    "qeft_oneshot_ipc_close": [_p],
+    "qeft_oneshot_allreduce_f32": [_p, _i, ctypes.POINTER(ctypes.c_void_p), _i, _i, _p, _p, _p],
 }
 
 _lib = None
@@ -98,7 +106,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name in ("qeft_error_string", "qeft_last_variant") else
                           ctypes.c_longlong if name in ("qeft_gemm_w4_workspace_bytes", "qeft_gemm_w4_dx_workspace_bytes",
-                                                       "qeft_gemv_v3_check_extents", "qeft_gemv_v3_check_extents_ckpt") else _i)
+                                                       "qeft_gemv_v3_check_extents", "qeft_gemv_v3_check_extents_ckpt",
+                                                       "qeft_oneshot_mailbox_bytes") else _i)
         _lib = l
     return _lib
 

@@ -423,7 +423,12 @@ class DecodeEngine:
     shapes) keep the round-1 scheme: every linear row-sharded, 4 all-gathers per layer.
     """
 
-    def __init__(self, model: QuantLlama, use_graph=True, tp_group=None):
+    def __init__(self, model: QuantLlama, use_graph=True, tp_group=None, collective="rccl"):
+        """collective (tensor-parallel only): "rccl" = torch.distributed's all_reduce on the group (RCCL ring over xGMI; gloo in the
+        one-GPU rehearsals), "oneshot" = the hand-written single-kernel all-reduce over IPC-mapped mailboxes (qeft_amd/oneshot.py,
+        SURVEY.md section 8e: the decode payload is 16 KB, latency-bound); `self.collective` says which one runs -- a request for
+        "oneshot" that cannot be served raises; "auto" tries it, checks it against the group's own all_reduce on a probe vector and
+        falls back to "rccl" on every rank alike, leaving the reason in `self.collective_note`."""
         import torch.distributed as dist
         from .sharded import shard_quantlinear
         self.m = model
@@ -500,6 +505,47 @@ class DecodeEngine:
         self.tp3 = (tp and self.bits == 4 and k_ok and s.n_out in (0, 128) and g_ == 128 and self.hs % 16 == 0
                     and self.kvs % 16 == 0 and self.its % 16 == 0 and self.its >= 128
                     and os.environ.get("QEFT_ENGINE_V2") != "1")
+        self.collective = "rccl" if tp else None
+        self.collective_note = None
+        self.oneshot = None
+        if self.tp3 and collective in ("oneshot", "auto") and self.sim_group is None:
+            # "auto": the one-shot kernel if every rank can build it AND it reproduces the group's own all_reduce on a probe vector;
+            # anything else falls back to the group's collective, and says so (collective_note)
+            from .oneshot import OneShotAllReduce
+            ok, why = True, None
+            try:
+                if self.P > self.lib.qeft_oneshot_max_world():
+                    raise ValueError(f"{self.P} ranks > {self.lib.qeft_oneshot_max_world()}")
+                self.oneshot = OneShotAllReduce(s.hidden, dev, tp_group)
+                probe = torch.randn(s.hidden, generator=torch.Generator().manual_seed(1234 + self.rank)).to(dev)
+                ref = probe.clone()
+                on_cpu = dist.get_backend(tp_group) == "gloo"
+                for _ in range(3):          # both mailbox parities
+                    self.oneshot.all_reduce(probe)
+                    r = ref.cpu() if on_cpu else ref
+                    dist.all_reduce(r, group=tp_group)
+                    ref = r.to(dev)
+                torch.cuda.synchronize(dev)
+                self.oneshot.check_status()
+                # (rank-order fp32 sum vs the ring's order: equal for two ranks, within rounding beyond)
+                if not torch.allclose(probe, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())):
+                    raise RuntimeError(f"probe mismatch: max |d| {(probe - ref).abs().max().item():.3e}")
+            except Exception as e:      # noqa: BLE001 -- any failure of the optional fast path means: use the group's collective
+                ok, why = False, f"{type(e).__name__}: {e}"[:200]
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            flag = flag if dist.get_backend(tp_group) == "gloo" else flag.to(dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=tp_group)        # every rank takes the same path
+            if int(flag.item()) == 1:
+                self.collective = "oneshot"
+            else:
+                if self.oneshot is not None:
+                    self.oneshot.close()
+                self.oneshot = None
+                self.collective_note = why or "another rank could not build the one-shot collective"
+                if collective == "oneshot":
+                    raise RuntimeError(f"collective='oneshot' was requested and is not available: {self.collective_note}")
+        elif tp and collective == "oneshot":
+            raise RuntimeError("collective='oneshot' needs the v3 tensor-parallel path and a real process group")
         if self.tp3:
             self.h32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)
             self.part32 = torch.zeros(s.hidden, dtype=torch.float32, device=dev)    # partial o_proj / down_proj output -> all-reduce
@@ -590,7 +636,9 @@ class DecodeEngine:
     def _all_reduce(self, t):
         """In-place sum over the tensor-parallel group (fp32 partial outputs; RCCL ring over xGMI, or the tests' stand-in)."""
         self.n_collectives += 1
-        if self.sim_group is not None:
+        if self.oneshot is not None:
+            self.oneshot.all_reduce(t)
+        elif self.sim_group is not None:
             self.sim_group.all_reduce(t)
         else:
             import torch.distributed as dist

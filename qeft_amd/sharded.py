@@ -50,9 +50,18 @@ class ShardedQuantLinear(nn.Module):
         self.outfeatures = full.outfeatures
         self.infeatures = full.infeatures
         self.local = shard_quantlinear(full, self.rank, self.world)
+        self._gather = {}       # rows -> [world, rows, N / world] gather buffer
 
     def forward(self, x):
-        y_loc = self.local(x).contiguous()
-        parts = [torch.empty_like(y_loc) for _ in range(self.world)]
-        dist.all_gather(parts, y_loc, group=self.group)
-        return torch.cat(parts, dim=-1)
+        """One collective, no per-call allocation beyond the output: the local rows land in a [world, m, N/P] buffer kept per batch
+        size (all_gather_into_tensor: hipGraph-capturable on RCCL), and the rank-major buffer is viewed back as [m, N]."""
+        y_loc = self.local(x)
+        lead = y_loc.shape[:-1]
+        y2 = y_loc.reshape(-1, y_loc.shape[-1]).contiguous()
+        m, nl = y2.shape
+        buf = self._gather.get(m)
+        if buf is None or buf.device != y2.device:
+            buf = torch.empty(self.world * m, nl, dtype=y2.dtype, device=y2.device)      # (rank-major concatenation: the form gloo takes too)
+            self._gather[m] = buf
+        dist.all_gather_into_tensor(buf, y2, group=self.group)
+        return buf.view(self.world, m, nl).permute(1, 0, 2).reshape(*lead, self.world * nl)
