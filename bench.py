@@ -308,7 +308,7 @@ def boundary_gemv_records(dev, sets=8, reps=20):
     """boundary_gemv: the reference's own entry points for < 8 rows, timed as a user of the reference reaches them --
     `qeft_cuda.gemv_4bit_qeft(x, qweight, scales, scaled_zeros, oweight_interleaved, m, N, K, G)` (qlinear.py:253-263) and
     `QuantLinear.forward` (forward_outlier; forward_outlier_out_proj with its reorder_ids gather for the o_proj record) at
-    m = 1 and 4 on the three 7B shapes.  `sets` distinct weight sets are cycled (nothing is served from L2 / MALL), the
+    m = 1, 2, 4 and 7 on the three 7B shapes.  `sets` distinct weight sets are cycled (nothing is served from L2 / MALL), the
     calls -- output allocation included -- are captured into a graph and replayed; HIP-event time per call, algorithmic
     bytes per call, and the kernel variant the call reached."""
     import torch
@@ -338,7 +338,7 @@ def boundary_gemv_records(dev, sets=8, reps=20):
                 qo.set_kernel()
                 oproj.append(qo)
         rec = {"shape": f"{n}x{k}"}
-        for m in (1, 4):
+        for m in (1, 2, 4, 7):
             x = torch.randn(m, k, device=dev).half()
             nbytes = n * (k - r) // 2 + 2 * (k // g) * n * 2 + n * r * 2 + 2 * m * k + 2 * m * n
             calls = {"gemv_4bit_qeft": lambda ql: qeft_cuda.gemv_4bit_qeft(x, ql.qweight, ql.scales, ql.scaled_zeros,

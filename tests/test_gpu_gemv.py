@@ -176,3 +176,32 @@ def test_gemv_rows_are_independent_of_sharding():
     got = torch.cat(parts, dim=-1)
     # fp32 sums are order-dependent only through the block shape; allow 1 fp16 ulp
     assert rel_err(got.cpu().numpy(), full.cpu().numpy()) < 1e-3
+
+
+def test_shim_scale_shadow_follows_the_tensors():
+    """gemv_4bit_qeft keeps a packed-scale shadow per (scales, zeros) pair of tensor objects (qeft_cuda._szp_shadow): the result is
+    the one of the shadow-free launch bit for bit, an in-place update of the scales is seen at the next call (version counter),
+    and a dead tensor leaves no entry behind."""
+    import gc
+    from qeft_amd import _lib, qeft_cuda
+    n, k = 512, 1024
+    bufs = O.make_layer(n, k, R, G, seed=21)
+    t = layer_to_torch(bufs, DEV)
+    x = torch.from_numpy(O.make_activation(1, k, R, seed=3)).to(DEV)
+    qeft_cuda._SZP_CACHE.clear()
+    y1 = qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"], 1, n, k, G)
+    assert len(qeft_cuda._SZP_CACHE) == 1 and _lib.last_variant() == "gemv_v3"
+    y2 = qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"], 1, n, k, G)      # hit
+    lib = _lib.lib()
+    y0 = torch.empty_like(y1)
+    _lib.check(lib.qeft_gemv_w4_qeft(x.data_ptr(), t["qweight"].data_ptr(), t["scales"].data_ptr(), t["scaled_zeros"].data_ptr(),
+                                     t["oweight_interleaved"].data_ptr(), y0.data_ptr(), 1, n, k, G, R, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0) and torch.equal(y2, y0)
+    t["scales"].mul_(2.0)                                 # in place: the shadow is stale now, the version counter says so
+    y3 = qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"], 1, n, k, G)
+    yref = O.quant_linear(x.cpu().numpy(), bufs["qweight"], t["scales"].cpu().numpy(), bufs["scaled_zeros"], bufs["oweight"], None, G)
+    assert rel_err(y3.cpu().numpy(), yref.astype(np.float64)) < REL_TOL
+    del t, y1, y2, y3
+    gc.collect()
+    assert len(qeft_cuda._SZP_CACHE) == 0
