@@ -291,12 +291,12 @@ def test_gemm_mid_m_tier_128_row_tiles(m, n, k, r, g):
     assert elem_err_ok(y, yref)
 
 
-@pytest.mark.parametrize("m,n,k,r,g", [(64, 4096, 4096, 128, 128), (200, 520, 1024, 128, 128), (100, 11008, 4096, 128, 128),
+@pytest.mark.parametrize("m,n,k,r,g", [(96, 4096, 4096, 128, 128), (200, 520, 1024, 128, 128), (100, 11008, 4096, 128, 128),
                                        (512, 4096, 11008, 128, 128), (17, 1000, 2048, 0, 256), (300, 4096, 1536, 64, 64)])
 def test_gemm_split_k_on_the_loader_wave_tile(m, n, k, r, g):
     """Fewer than 192 tiles of 128 x 128: S blocks per tile contract K / S each (the fp16 outlier k-tiles fall to the last one),
-    fp32 partial tiles through the workspace, the ordered reduce launch (round 3; deterministic).  M = 17 .. 512 incl. the
-    64-token prompt of benchmark.py, ragged M and N, S = 2 .. 8, no outlier slice / 64 columns; full output vs the oracle."""
+    fp32 partial tiles through the workspace, the ordered reduce launch (round 3; deterministic).  M = 17 .. 512 (17 .. 64 rows of a
+    group-128 shape go to the weight-stationary tier since round 4: the 17-row case here has group 256), ragged M and N, S = 2 .. 8, no outlier slice / 64 columns; full output vs the oracle."""
     from qeft_amd import _lib, qeft_cuda
     bufs = O.make_layer(n, k, r, g, seed=m + n + k, bias=True)
     t = layer_to_torch(bufs, DEV)

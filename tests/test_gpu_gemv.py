@@ -184,7 +184,7 @@ def test_shim_scale_shadow_follows_the_tensors():
     and a dead tensor leaves no entry behind."""
     import gc
     from qeft_amd import _lib, qeft_cuda
-    n, k = 512, 1024
+    n, k, R, G = 512, 1024, 128, 128
     bufs = O.make_layer(n, k, R, G, seed=21)
     t = layer_to_torch(bufs, DEV)
     x = torch.from_numpy(O.make_activation(1, k, R, seed=3)).to(DEV)
