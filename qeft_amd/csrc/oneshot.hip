@@ -107,7 +107,12 @@ int qeft_oneshot_mailbox_alloc(int world, int n, void** dev_ptr_out) {
     if (!dev_ptr_out) return QEFT_ERR_NULL;
     const long long bytes = qeft_oneshot_mailbox_bytes(world, n);
     if (bytes <= 0) return QEFT_ERR_SHAPE;
-    if (hipMalloc(dev_ptr_out, (size_t)bytes) != hipSuccess) return QEFT_ERR_LAUNCH;
+    // FINE-GRAINED device memory (what RCCL uses for its peer-visible buffers): remote stores over xGMI and the owner's polling
+    // loads stay coherent without a kernel boundary; coarse-grained memory is only guaranteed coherent at kernel boundaries
+    if (hipExtMallocWithFlags(dev_ptr_out, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(dev_ptr_out, (size_t)bytes) != hipSuccess) return QEFT_ERR_LAUNCH;
+    }
     if (hipMemset(*dev_ptr_out, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return QEFT_ERR_LAUNCH;
     return QEFT_OK;
 }
