@@ -209,6 +209,13 @@ int qeft_single_query_attention_alibi(const void* q, const void* k, const void* 
                                       int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
                                       int n_kv_heads, int max_seq, const float* alibi_slopes, qeft_stream_t stream);
 
+/* qeft_single_query_attention_generic (round 4): the same boundary for the other head sizes the reference instantiates
+ * (ft_attention.cpp:110-181: 32 .. 256): any head_dim % 8 == 0 in [8, 256], caches k [n_kv][head_dim/8][max_seq][8],
+ * v [n_kv][max_seq][head_dim], NO rotary inside (the shim rotates q / k first), optional alibi_slopes (NULL: none). */
+int qeft_single_query_attention_generic(const void* q, const void* k, const void* v, void* k_cache_ft, void* v_cache, const int* pos,
+                                        void* out, int n_heads, int n_kv_heads, int max_seq, int head_dim, const float* alibi_slopes,
+                                        qeft_stream_t stream);
+
 /* ---- v3 decode linear (batch 1): the decode engine's production GEMV (csrc/gemv_v3.h) ------------------------------
  *     y[n] = Wdeq . x (+ bias)                                          (gemv_4bit_qeft, gemv_cuda_qeft.cu:392-513, m = 1)
  * reads the fp16 vector x[k] AS IT IS (no transform of x inside); the decoder's element-wise neighbours sit in the EPILOGUE

@@ -68,6 +68,7 @@ SIGNATURES = {
     "qeft_residual_norm": [_p, _p, _p, _p, _p, _p, _i, _p],
     "qeft_single_query_attention": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     "qeft_single_query_attention_alibi": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "qeft_single_query_attention_generic": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "qeft_rope_attn_decode": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "qeft_oneshot_mailbox_bytes": [_i, _i],
     "qeft_oneshot_max_world": [],

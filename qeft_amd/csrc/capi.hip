@@ -42,6 +42,8 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
                                    int n_kv, int max_seq, int S, int tab_rows, hipStream_t st, bool k_ft_layout = false,
                                    const float* alibi_slopes = nullptr);
 size_t attn_workspace_bytes(int n_heads, int S);
+hipError_t sqa_generic_launch(const void* q, const void* k, const void* v, void* kc, void* vc, const int* pos, const float* alibi,
+                              void* out, int n_heads, int n_kv, int max_seq, int head_dim, hipStream_t st);
 hipError_t token_begin_launch(const void* embed, const void* tok, const void* rope_tab, const int* pos, void* h,
                               void* rope_row, int hidden, int vocab, int max_seq, hipStream_t st);
 hipError_t token_end_launch(const void* logits, void* tok, int* pos, int vocab, int greedy, hipStream_t st);
@@ -675,6 +677,19 @@ int qeft_single_query_attention(const void* q, const void* k, const void* v, con
                                 int tab_rows, void* k_cache_ft, void* v_cache, const int* pos, void* out, int n_heads,
                                 int n_kv_heads, int max_seq, qeft_stream_t stream) {
     return sqa_impl(q, k, v, cos_tab, sin_tab, tab_rows, k_cache_ft, v_cache, pos, out, n_heads, n_kv_heads, max_seq, nullptr, stream);
+}
+
+int qeft_single_query_attention_generic(const void* q, const void* k, const void* v, void* k_cache_ft, void* v_cache, const int* pos,
+                                        void* out, int n_heads, int n_kv_heads, int max_seq, int head_dim, const float* alibi_slopes,
+                                        qeft_stream_t stream) {
+    if (!q || !k || !v || !k_cache_ft || !v_cache || !pos || !out) return QEFT_ERR_NULL;
+    if (n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || head_dim < 8 || head_dim > 256 || head_dim % 8 != 0 ||
+        max_seq < 1 || max_seq > 32768)
+        return QEFT_ERR_SHAPE;
+    if (!aligned16(k_cache_ft) || !aligned16(v_cache)) return QEFT_ERR_ALIGN;
+    qeft::g_last_variant = "sqa_generic";
+    return finish(qeft::sqa_generic_launch(q, k, v, k_cache_ft, v_cache, pos, alibi_slopes, out, n_heads, n_kv_heads, max_seq, head_dim,
+                                           (hipStream_t)stream));
 }
 
 int qeft_single_query_attention_alibi(const void* q, const void* k, const void* v, const void* cos_tab, const void* sin_tab,

@@ -731,4 +731,106 @@ hipError_t rope_attn_decode_launch(const void* q, const void* k, const void* v, 
     return launch(rope_attn_decode_kernel<1>);
 }
 
+// ---- single-query attention for head sizes other than 128 (round 4; the `qeft_cuda.single_query_attention` boundary only).
+// The reference instantiates its FasterTransformer kernel for Dh = 32 .. 256 (ft_attention.cpp:110-181,
+// decoder_masked_multihead_attention.cu:30-59); the decode engine's kernel above is built around Dh = 128 (Llama-2).  This one
+// takes any Dh % 8 == 0, 8 <= Dh <= 256: one block per head, the reference's cache layouts (keys [n_kv][Dh/8][L][8], values
+// [n_kv][L][Dh]), no rotary (the shim rotates q / k with torch ops first, as it does for partial / GPT-J rotary at Dh = 128),
+// optional ALiBi.  The block of a group's first head appends k / v at *pos; every block takes position *pos from the call's
+// own k / v (not from the cache), so no block depends on another's stores.  Correctness first: scores one position per
+// thread, P.V one (position class, dim) per thread, two LDS reductions.
+__global__ __launch_bounds__(256) void sqa_generic_kernel(const f16* __restrict__ q, const f16* __restrict__ k, const f16* __restrict__ v,
+                                                          f16* __restrict__ kc, f16* __restrict__ vc, const int* __restrict__ pos_ptr,
+                                                          const float* __restrict__ alibi, f16* __restrict__ out, int n_heads, int n_kv,
+                                                          int max_seq, int D) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    float* qs = (float*)smem_raw;                 // [D] scaled q
+    float* knew = qs + 256;                       // [D]
+    float* vnew = knew + 256;                     // [D]
+    float* red = vnew + 256;                      // [256]
+    float* prob = red + 256;                      // [max_seq]
+    const int h = blockIdx.x, t = threadIdx.x;
+    const int grp = n_heads / n_kv, hk = h / grp;
+    const int pos = *pos_ptr, L = pos + 1;
+    if (pos < 0 || pos >= max_seq) return;
+    f16* kch = kc + (size_t)hk * max_seq * D;
+    f16* vch = vc + (size_t)hk * max_seq * D;
+    const float scale = __builtin_amdgcn_rsqf((float)D);
+    if (t < D) {
+        const f16 kv = k[hk * D + t], vv = v[hk * D + t];
+        qs[t] = (float)q[h * D + t] * scale;
+        knew[t] = (float)kv;
+        vnew[t] = (float)vv;
+        if (h % grp == 0) {
+            kch[((size_t)(t >> 3) * max_seq + pos) * 8 + (t & 7)] = kv;
+            vch[(size_t)pos * D + t] = vv;
+        }
+    }
+    __syncthreads();
+    const float slope = alibi ? alibi[h] : 0.f;
+    float lmax = -3.0e38f;
+    for (int p = t; p < L; p += 256) {
+        float sdot = 0.f;
+        if (p == pos) {
+            for (int d = 0; d < D; ++d) sdot += qs[d] * knew[d];
+        } else {
+            for (int c = 0; c < D / 8; ++c) {
+                const h8 kk = *(const h8*)(kch + ((size_t)c * max_seq + p) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sdot += qs[c * 8 + e] * (float)kk[e];
+            }
+        }
+        sdot += slope * (float)(p - pos);
+        prob[p] = sdot;
+        lmax = fmaxf(lmax, sdot);
+    }
+    red[t] = lmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+        __syncthreads();
+    }
+    const float m = red[0];
+    __syncthreads();
+    float lsum = 0.f;
+    for (int p = t; p < L; p += 256) {
+        const float e = __expf(prob[p] - m);
+        prob[p] = e;
+        lsum += e;
+    }
+    red[t] = lsum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        __syncthreads();
+    }
+    const float inv = 1.f / red[0];
+    __syncthreads();
+    // P.V: thread = (position class pcl = t / D, dim d = t % D); NG classes share the positions
+    const int NG = 256 / D > 0 ? 256 / D : 1;
+    float o = 0.f;
+    const int d = t % D, pcl = t / D;
+    if (pcl < NG)
+        for (int p = pcl; p < L; p += NG) o += prob[p] * (p == pos ? vnew[d] : (float)vch[(size_t)p * D + d]);
+    red[t] = pcl < NG ? o : 0.f;
+    __syncthreads();
+    if (t < D) {
+        float acc = 0.f;
+        for (int g = 0; g < NG; ++g) acc += red[g * D + t];
+        out[h * D + t] = (f16)(acc * inv);
+    }
+}
+
+hipError_t sqa_generic_launch(const void* q, const void* k, const void* v, void* kc, void* vc, const int* pos, const float* alibi,
+                              void* out, int n_heads, int n_kv, int max_seq, int head_dim, hipStream_t st) {
+    const size_t smem = (size_t)(4 * 256 + max_seq) * 4;
+    if (smem > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void*)sqa_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sqa_generic_kernel, dim3(n_heads), dim3(256), smem, st, (const f16*)q, (const f16*)k, (const f16*)v, (f16*)kc, (f16*)vc,
+                       pos, alibi, (f16*)out, n_heads, n_kv, max_seq, head_dim);
+    return hipGetLastError();
+}
+
 }  // namespace qeft

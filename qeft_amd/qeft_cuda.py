@@ -450,11 +450,13 @@ def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_
     Rotary: the neox style over the whole head (Llama: rotary_embedding_dim 128) or none (0) runs inside the kernel; a partial
     rotary_embedding_dim (even, < 128) and the interleaved GPT-J style (neox_rotary_style=False) are rotated here with a few
     torch ops (fp32 math, rounded to half as the reference's kernel does) in front of a launch without rotary.
-    Not supported (RuntimeError): head sizes other than 128, fp32 / bf16."""
+    Head sizes other than 128 (any multiple of 8 up to 256: the reference instantiates 32 .. 256, ft_attention.cpp:110-181) take
+    the generic kernel (qeft_single_query_attention_generic): rotary always applied here first, ALiBi inside.
+    Not supported (RuntimeError): fp32 / bf16, head sizes that are not a multiple of 8 or exceed 256."""
     _need(q.is_cuda and q.dtype == torch.float16, "single_query_attention: only Half GPU tensors are supported")
     B, Hkv, L, D = v_cache.shape
     H = q.shape[1]
-    _need(D == 128, "single_query_attention: head_dim must be 128")
+    _need(D % 8 == 0 and 8 <= D <= 256, "single_query_attention: head_dim must be a multiple of 8 in [8, 256]")
     rot = int(rotary_embedding_dim)
     _need(0 <= rot <= D and rot % 2 == 0, "single_query_attention: rotary_embedding_dim must be an even number in [0, head_dim]")
     if alibi_slopes_ is not None:
@@ -475,7 +477,7 @@ def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_
     else:
         _need(0 <= int(timestep) < L, f"timestep {timestep} outside the cache (length {L})")
         pos = torch.full((B,), int(timestep), dtype=torch.int32, device=q.device)
-    in_kernel = rot == 0 or (rot == D and neox_rotary_style)
+    in_kernel = rot == 0 or (D == 128 and rot == D and neox_rotary_style)
     if not in_kernel:
         # rotate here: pairs (i, i + rot/2) (neox) or (2i, 2i + 1) (GPT-J) of the first `rot` dims, angle pos * base^(-2i/rot)
         half = rot // 2
@@ -494,8 +496,17 @@ def single_query_attention(q, k, v, k_cache, v_cache, length_per_sample_, alibi_
                 o[..., 0:rot:2], o[..., 1:rot:2] = ra, rb
             return o.half().contiguous()
         q, k = rotate(q), rotate(k)
-    tab = _rope_table(q.device, rot if in_kernel else 0, rotary_base, L)
     out = torch.empty_like(q)
+    if D != 128:
+        with torch.cuda.device(q.device):
+            lib, st = _lib.lib(), _stream(q)
+            for b in range(B):
+                _lib.check(lib.qeft_single_query_attention_generic(
+                    q[b].data_ptr(), k[b].data_ptr(), v[b].data_ptr(), k_cache[b].data_ptr(), v_cache[b].data_ptr(),
+                    pos.data_ptr() + 4 * b, out[b].data_ptr(), H, Hkv, L, D,
+                    alibi_slopes_.data_ptr() if alibi_slopes_ is not None else None, st))
+        return out
+    tab = _rope_table(q.device, rot if in_kernel else 0, rotary_base, L)
     with torch.cuda.device(q.device):
         lib, st = _lib.lib(), _stream(q)
         for b in range(B):      # the kernel serves one sequence per launch (decode harness); the batch is a host loop

@@ -402,7 +402,7 @@ def test_shim_layernorm_forward_cuda():
 @pytest.mark.parametrize("B,H,Hkv,rot,neox,alibi", [(1, 4, 4, 128, True, False), (2, 8, 2, 128, True, False), (1, 2, 2, 0, True, False),
                                                      (2, 4, 2, 128, True, True), (1, 4, 4, 0, True, True), (2, 4, 2, 64, True, False),
                                                      (1, 4, 4, 128, False, False), (2, 4, 4, 32, False, True)])
-def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot, neox, alibi):
+def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot, neox, alibi, D=128):
     """Positional call exactly as ftllama_modeling.py:139-153 makes it, caches in the reference's layouts
     (k_cache [B, Hkv, Dh/8, L, 8], v_cache [B, Hkv, L, Dh]); checked against a plain fp32 PyTorch decode -- the neox rotary
     of the Llama path, no rotary, a partial rotary_embedding_dim, the interleaved GPT-J style
@@ -410,7 +410,7 @@ def test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot, neox
     (decoder_masked_multihead_attention_template.hpp:1335-1345: slope * (key - query position) on the scaled score)."""
     import math
     import qeft_cuda
-    D, L, T = 128, 64, 21
+    L, T = 64, 21
     torch.manual_seed(B * 10 + H)
     k_cache = torch.zeros(B, Hkv, D // 8, L, 8, dtype=torch.float16, device=DEV)
     v_cache = torch.zeros(B, Hkv, L, D, dtype=torch.float16, device=DEV)
@@ -493,3 +493,14 @@ def test_multi_token_graphs_equal_single_token_steps():
     assert torch.equal(a.logits, b.logits) and torch.equal(a.pos, b.pos)
     for li in range(shape.n_layers):
         assert torch.equal(a.kc[li][:, :24], b.kc[li][:, :24]) and torch.equal(a.vc[li][:, :24], b.vc[li][:, :24])
+
+
+@pytest.mark.parametrize("D,B,H,Hkv,rot,neox,alibi", [(64, 2, 4, 2, 64, True, False), (96, 1, 4, 4, 32, False, True), (32, 1, 8, 8, 0, True, False),
+                                                       (256, 2, 2, 1, 256, True, False), (80, 1, 4, 2, 80, True, True), (192, 1, 2, 2, 64, True, False)])
+def test_shim_single_query_attention_other_head_sizes(D, B, H, Hkv, rot, neox, alibi):
+    """The head sizes the reference instantiates besides 128 (ft_attention.cpp:110-181: 32 .. 256) through the generic kernel
+    (round 4): the same checks as the 128 case -- outputs vs a plain fp32 PyTorch decode over 21 steps, the caches' contents in
+    the reference's layouts, per-sample lengths, the argument errors."""
+    test_shim_single_query_attention_reference_cache_layout(B, H, Hkv, rot, neox, alibi, D=D)
+    from qeft_amd import _lib
+    assert _lib.last_variant() == "sqa_generic"

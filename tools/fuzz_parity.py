@@ -39,6 +39,44 @@ if len(sys.argv) > 2 and sys.argv[2] == "v3":
             fails.append((case, n, k, r, e))
     print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
     sys.exit(1 if fails else 0)
+if len(sys.argv) > 2 and sys.argv[2] == "ws":
+    # round 4: the weight-stationary tier (gemm_ws.hip) at the GEMM entries: 17..64 rows, N % 16, K % 128, group 128, r in {0, 128},
+    # bias on / off, through gemm_4bit_qeft (fused outlier) and gemm_4bit (no slice); every output element against the oracle
+    for case in range(CASES):
+        n = 16 * int(rng.integers(1, 901))
+        k = 128 * int(rng.integers(2, 91))
+        r = int(rng.choice([0, 128, 128]))
+        m = int(rng.integers(17, 65))
+        bias = bool(rng.integers(0, 2))
+        b = O.make_layer(n, k, r, 128, seed=case, bias=bias)
+        t = layer_to_torch(b, DEV)
+        x = O.make_activation(m, k, max(r, 1), seed=case)
+        xt = torch.from_numpy(x).to(DEV)
+        if r:
+            y = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight"], t.get("bias"))
+        elif bias:
+            y = qeft_cuda.gemm_4bit_qeft(xt, t["qweight"], t["scales"], t["scaled_zeros"], None, t.get("bias"))
+        else:
+            y = qeft_cuda.gemm_4bit(xt, t["qweight"], t["scales"], t["scaled_zeros"])
+        v = _lib.last_variant()
+        torch.cuda.synchronize()
+        ref = O.quant_linear(x, b["qweight"], b["scales"], b["scaled_zeros"], b.get("oweight") if r else None, b.get("bias"), 128).astype(np.float64)
+        got = y.cpu().numpy()
+        e = rel_err(got, ref)
+        # element-wise: tests/util.elem_err_ok's allowance (1e-3 |ref| + 1e-3 rms).  With up to 10^6 outputs per case the tail of the
+        # accumulation noise of the 1024 + q trick (fp32 partial sums of magnitude 1e4, K up to 11520) crosses it by a few per cent on
+        # about one element in 10^6: reported (`over`), and a case fails if more than 1e-5 of its elements cross or any by 2 x
+        d = np.abs(got - ref)
+        allow = 1e-3 * np.abs(ref) + 1e-3 * float(np.sqrt(np.mean(ref ** 2)))
+        over = int((d > allow).sum())
+        worst = float((d / allow).max())
+        ok = e < 1e-3 and over <= 1e-5 * d.size and worst < 2.0 and v == "gemm_ws"
+        seen[v] = seen.get(v, 0) + 1
+        print(f"case {case:3d} m={m:2d} n={n:5d} k={k:5d} r={r:3d} bias={int(bias)}  {v:8s} y={e:.1e} over={over} worst={worst:.2f}" + ("" if ok else "   FAIL"), flush=True)
+        if not ok:
+            fails.append((case, m, n, k, r, e))
+    print(f"{CASES} cases, {len(fails)} failures, {time.time() - t0:.0f} s; variants reached: {seen}")
+    sys.exit(1 if fails else 0)
 if len(sys.argv) > 2 and sys.argv[2] == "ref":
     # round 3: the REFERENCE's gemv entries (gemv_4bit / gemv_4bit_qeft / the fused form) on the v3 kernel's domain -- operands as
     # the checkpoint holds them: m = 1..7, group 128 or per-channel, r in {0, 128}, with / without gather, bias, sz_packed shadow
