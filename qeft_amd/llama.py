@@ -972,7 +972,7 @@ class DecodeEngine:
             self._launch_token()
         self.host_pos += 1
 
-    MULTI = 8       # tokens per multi-token graph (greedy decoding only)
+    MULTI = int(os.environ.get("QEFT_MULTI_TOKENS", "8"))       # tokens per multi-token graph (greedy decoding only; 16 / 32 measured in round 4)
 
     def run(self, n_tokens):
         """Greedy decoding of n_tokens tokens (self.greedy must be set): like n_tokens calls of step(), but with hipGraphs of
