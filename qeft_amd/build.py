@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libqeft_hip.so")
 SOURCES = ["capi.hip", "gemv_w4.hip", "gemv_v3.hip", "gemv_v3_plain.hip", "gemv_w3.hip", "gemm_w4.hip", "gemm_ws.hip", "aux_w4.hip", "decode_aux.hip", "oneshot.hip"]
-HEADERS = ["qeft_common.h", "gemv_w4_kernel.h", "gemv_w4_mfma.h", "gemv_v3.h", "gemv_v3_dispatch.h", os.path.join("..", "..", "include", "qeft_hip.h")]
+HEADERS = ["qeft_common.h", "gemv_w4_kernel.h", "gemv_w4_mfma.h", "gemv_v3.h", "gemv_v3_dispatch.h", "decode_attn.h", os.path.join("..", "..", "include", "qeft_hip.h")]
 ARCH = "gfx950"
 
 
