@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const f16* __restrict__ x,
         const h8 g = *(const h8*)(gamma + i);
         h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * rs * (float)g[j]);
+        for (int j = 0; j < 8; ++j) o[j] = mul_f32_to_f16((float)v[j] * rs, (float)g[j]);
         *(h8*)(y + base + i) = o;
     }
 }
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const f16* __restrict__ g
     h8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        o[j] = (f16)(silu_f32((float)g[j]) * (float)u[j]);
+        o[j] = mul_f32_to_f16(silu_f32((float)g[j]), (float)u[j]);
     }
     *(h8*)(out + i) = o;
 }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void token_begin_norm_kernel(const f16* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             ss += (float)v[j] * (float)v[j];
-            o[j] = (f16)((float)v[j] * (float)g[j]);
+            o[j] = mul_f32_to_f16((float)v[j], (float)g[j]);
             h[i + j] = (float)v[j];
         }
         *(h8*)(hnorm + i) = o;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void residual_norm_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 ss += v[j] * v[j];
-                o[j] = (f16)(v[j] * (float)g[j]);
+                o[j] = mul_f32_to_f16(v[j], (float)g[j]);
             }
             *(h8*)(hnorm + i) = o;
         }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restric
     for (int i = threadIdx.x; i < H; i += 256) ss += x[base + i] * x[base + i];
     ss = block_sum_256(ss, sm);
     const float rs = rsqrtf(ss / (float)H + eps);
-    for (int i = threadIdx.x; i < H; i += 256) y[base + i] = (f16)(x[base + i] * rs * (float)gamma[i]);
+    for (int i = threadIdx.x; i < H; i += 256) y[base + i] = mul_f32_to_f16(x[base + i] * rs, (float)gamma[i]);
 }
 
 // Rotary embedding of a whole prompt, in place: x [T][H][128] fp16, cos / sin [T][64] fp32 (NeoX pairing i, i + 64; fp32
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512) void lm_head_f16_kernel(const float* __restric
         const h8 g = *(const h8*)(gamma + c * 512 + lane * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)             // the rounding of qeft_rmsnorm_f32: fp16(x * rs * gamma)
-            xh[c][j] = h2{(f16)(xv[c][2 * j] * rs * (float)g[2 * j]), (f16)(xv[c][2 * j + 1] * rs * (float)g[2 * j + 1])};
+            xh[c][j] = h2{mul_f32_to_f16(xv[c][2 * j] * rs, (float)g[2 * j]), mul_f32_to_f16(xv[c][2 * j + 1] * rs, (float)g[2 * j + 1])};
     }
     (void)red;
     const int r_end = min(vocab, (int)(blockIdx.x + 1) * rows_per_block);

@@ -851,7 +851,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
                 const h8 u = __builtin_bit_cast(h8, *(const u32x4*)(lds + row * G3_YP + ch * 16)), gv = __builtin_bit_cast(h8, g[j]);
                 h8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)(silu_f32((float)gv[e]) * (float)u[e]);
+                for (int e = 0; e < 8; ++e) o[e] = mul_f32_to_f16(silu_f32((float)gv[e]), (float)u[e]);
                 *(h8*)(y + (size_t)m * N + n0) = o;
             }
         };
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(512) void gemm_w4_kernel_v3(const f16* __restrict__
             const h8 u = __builtin_bit_cast(h8, *(const u32x4*)(lds + row * G3_YP + 128 + ch * 16));
             h8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(silu_f32((float)gv[e]) * (float)u[e]);
+            for (int e = 0; e < 8; ++e) o[e] = mul_f32_to_f16(silu_f32((float)gv[e]), (float)u[e]);
             *(h8*)(y + (size_t)m * nh + n0) = o;
         }
     }

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             h4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j] = (f16)(hv[j] * (float)gv[j]);
+                o[j] = mul_f32_to_f16(hv[j], (float)gv[j]);
                 xn_ss += hv[j] * hv[j];
             }
             *(h4*)(xs + (size_t)e * 2) = o;
@@ -556,8 +556,12 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         // three steps ahead (an L2 round trip under load is ~1 us, a step a few hundred ns)
         constexpr int XP = XG ? 4 : 2, XD = XP - 1;
         v3h8 xr[XP][4];
-        val_t alo = v3_zero<MB>(), ahi = v3_zero<MB>();        // -1024 S_lo, -1024 S_hi of the current step
-        val_t nlo = v3_zero<MB>(), nhi = v3_zero<MB>();        // the next step's sums, computed one step ahead
+        // -1024 S_lo, -1024 S_hi of the current step's x fragments (S = the sum of x over the low- / high-nibble positions), kept
+        // as the whole MFMA result: they are the C operand of the step's product MFMAs, so P comes out as sum x q with the
+        // 1024 bias already gone and the fold never touches them; cB = -sum(x) of the step for the zero-point term
+        f32x4 clo = z4, chi = z4;
+        f32x4 nlo = z4, nhi = z4;                               // the next step's, computed one step ahead
+        val_t cB = v3_zero<MB>();
         // LDS addresses of the wave's current step: x fragments (256 B per step) and the set-0 scale words (64 B per step / group)
         const uint8_t* xp = xa + (size_t)wave * 256;
         const uint8_t* sp = szl + (size_t)(per_channel ? 0 : wave) * 64 + nl * 4;
@@ -567,19 +571,13 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
 #pragma unroll
             for (int w = 0; w < 4; ++w) o[w] = px[w];
         };
-        auto bias_sums = [&](const v3h8 (&x4)[4], val_t& lo, val_t& hi) {
-            f32x4 A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[0], c8, z4, 0, 0, 0);
-            f32x4 A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[1], c8, z4, 0, 0, 0);
-            A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, A0, 0, 0, 0);
-            A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[3], c8, A1, 0, 0, 0);
-            if (BITS == 3) {                // one scale class: every 3-bit field is moved to bits 0..2 of its half-word
-                lo = v3_pick<MB>(A0) + v3_pick<MB>(A1);
-                hi = v3_zero<MB>();
-            } else {
-                lo = v3_pick<MB>(A0);
-                hi = v3_pick<MB>(A1);
-            }
+        auto bias_sums = [&](const v3h8 (&x4)[4], f32x4& lo, f32x4& hi) {
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[0], c8, z4, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[1], c8, z4, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[3], c8, hi, 0, 0, 0);
         };
+        auto zero_term = [&](const f32x4& lo, const f32x4& hi) { return (v3_pick<MB>(lo) + v3_pick<MB>(hi)) * -0.0009765625f; };
         // XG: address of the fragments of the step XD ahead, clamped to the wave's last step
         const uint8_t* const xlast = xp + (size_t)(nsw - 1) * (NW * 256);
         const uint8_t* xq = xp;
@@ -592,14 +590,15 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             xq = xq + NW * 256 <= xlast ? xq + NW * 256 : xlast;
         }
         uint32_t szw = *(const uint32_t*)sp;                   // scale word of the next consume
-        bias_sums(xr[0], alo, ahi);
+        bias_sums(xr[0], clo, chi);
+        cB = zero_term(clo, chi);
         // Software pipeline: the products of a (step, row set) are folded into the accumulators one consume LATER, behind
         // the MFMAs of the next one -- nothing reads an MFMA result right behind the MFMA (that wait was ~10 % of a launch).
-        val_t pv_lo = v3_zero<MB>(), pv_hi = v3_zero<MB>(), pv_alo = v3_zero<MB>(), pv_ahi = v3_zero<MB>();
+        val_t pv_lo = v3_zero<MB>(), pv_hi = v3_zero<MB>(), pv_B = v3_zero<MB>();
         uint32_t pv_szw = 0;
         auto fold = [&](val_t& dst) {
             const h2 sz2 = as_h2(pv_szw);
-            dst = dst + ((float)sz2[0] * ((pv_lo + pv_alo) + 0.0625f * (pv_hi + pv_ahi)) + (float)sz2[1] * ((pv_alo + pv_ahi) * -0.0009765625f));
+            dst = dst + ((float)sz2[0] * (pv_lo + 0.0625f * pv_hi) + (float)sz2[1] * pv_B);
         };
         // one (step, row set): xc = the step's fragments, xnx = the next step's (fetched at the step's first row set, their bias
         // sums formed behind its last); prev_rs = the row set of the previous consume (whose products are folded here)
@@ -645,8 +644,8 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
 #pragma unroll
                         for (int w = 0; w < 4; ++w) bf[j][w] = ext[4 * j + w];
                 }
-                f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
-                f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
+                f32x4 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[0], __builtin_bit_cast(v3h8, bf[0]), clo, 0, 0, 0);
+                f32x4 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[1], __builtin_bit_cast(v3h8, bf[1]), chi, 0, 0, 0);
                 Plo = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[2], __builtin_bit_cast(v3h8, bf[2]), Plo, 0, 0, 0);
                 Phi = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[3], __builtin_bit_cast(v3h8, bf[3]), Phi, 0, 0, 0);
                 if (rs == RSC - 1) bias_sums(xnx, nlo, nhi);    // the NEXT step's sums ride behind this step's last products
@@ -659,12 +658,13 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                     hi = v3_pick<MB>(Phi);
                 }
             }
-            pv_lo = lo; pv_hi = hi; pv_alo = alo; pv_ahi = ahi; pv_szw = szw;
+            pv_lo = lo; pv_hi = hi; pv_B = cB; pv_szw = szw;
             szw = szw_n;
             issue(slot, std::integral_constant<int, (rs + D) % RSC>{});      // the slot's next load: number c + D of the sequence
             if (rs == RSC - 1) {                                // step done
-                alo = nlo;
-                ahi = nhi;
+                clo = nlo;
+                chi = nhi;
+                cB = zero_term(nlo, nhi);
                 if (more_steps) { xp += NW * 256; sp += s_stride; }
                 if constexpr (XG) xq = xq + NW * 256 <= xlast ? xq + NW * 256 : xlast;
             }
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
                 uv += (float)bias[(set0 + rs) * 16 + 8 + n];
             }
             const f16 g16 = (f16)gv, u16 = (f16)uv;
-            const f16 r16 = (f16)(silu_f32((float)g16) * (float)u16);
+            const f16 r16 = mul_f32_to_f16(silu_f32((float)g16), (float)u16);
             V3_STAMP_VALUE(r16);
             yout[(set0 + rs) * 8 + n] = r16;
         }
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             v += ((const float*)epl)[tid];                          // lanes [0, 16) x 4 floats = the block's RS * 16 rows
             y32[row] = v;
             if (gamma_out) {
-                ynorm[row] = (f16)(v * (float)((const f16*)(epl + 256))[tid]);
+                ynorm[row] = mul_f32_to_f16(v, (float)((const f16*)(epl + 256))[tid]);
                 sq = v * v;
             }
         } else {

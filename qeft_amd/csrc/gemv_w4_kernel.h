@@ -146,7 +146,7 @@ __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const h2 t = as_h2(xst[p][j]), gm = as_h2(ast[p][j]);
-                xst[p][j] = as_u32(h2{(f16)((float)t[0] * rs * (float)gm[0]), (f16)((float)t[1] * rs * (float)gm[1])});
+                xst[p][j] = as_u32(h2{mul_f32_to_f16((float)t[0] * rs, (float)gm[0]), mul_f32_to_f16((float)t[1] * rs, (float)gm[1])});
             }
         }
     } else if (XT == 2) {
@@ -156,7 +156,7 @@ __device__ __forceinline__ void gemv_w4_body(const GemvArgs& a, const int blk) {
             for (int j = 0; j < 4; ++j) {
                 const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
                 const float g0 = (float)t[0], g1 = (float)t[1];
-                xst[p][j] = as_u32(h2{(f16)(silu_f32(g0) * (float)u[0]), (f16)(silu_f32(g1) * (float)u[1])});
+                xst[p][j] = as_u32(h2{mul_f32_to_f16(silu_f32(g0), (float)u[0]), mul_f32_to_f16(silu_f32(g1), (float)u[1])});
             }
         }
     }

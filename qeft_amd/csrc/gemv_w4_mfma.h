@@ -211,7 +211,7 @@ __device__ __forceinline__ void gemv_w4_mfma_body(const GemvArgs& a, const int s
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const h2 t = as_h2(xst[p][j]), u = as_h2(ast[p][j]);
-                    xst[p][j] = as_u32(h2{(f16)(silu_f32((float)t[0]) * (float)u[0]), (f16)(silu_f32((float)t[1]) * (float)u[1])});
+                    xst[p][j] = as_u32(h2{mul_f32_to_f16(silu_f32((float)t[0]), (float)u[0]), mul_f32_to_f16(silu_f32((float)t[1]), (float)u[1])});
                 }
             }
     }

@@ -130,5 +130,13 @@ __device__ __forceinline__ float dot2(h2 a, h2 b, float c) { return __builtin_am
 // silu(g) = g / (1 + e^-g) in fp32 with the hardware reciprocal (1 ulp) instead of an IEEE division: the result is
 // rounded to fp16 right after, and a division costs ~10 VALU instructions in a prologue every block repeats.
 __device__ __forceinline__ float silu_f32(float g) { return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
+// fp16(a * b) with the product rounded to fp32 FIRST -- what torch (and the reference's RMSNorm) computes.  Written out because
+// hipcc may otherwise pick v_fma_mixlo_f16 (one rounding, different in 1 of ~10^4 values), and whether it does changes with the
+// code around it: the norm outputs of different kernels (GEMV epilogue, residual_norm, token_begin) must agree bit for bit.
+__device__ __forceinline__ f16 mul_f32_to_f16(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return (f16)p;
+}
 
 }  // namespace qeft
