@@ -264,11 +264,12 @@ template <> struct V3Val<2> { typedef f32x4 type; };
 template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_pick(const f32x4& v) {
     if constexpr (MB == 1) return v[0]; else return v;
 }
+template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_fma_s(float a, typename V3Val<MB>::type b, typename V3Val<MB>::type c) {
+    if constexpr (MB == 1) return __builtin_fmaf(a, b, c); else return __builtin_elementwise_fma(f32x4{a, a, a, a}, b, c);
+}
 template <int MB> __device__ __forceinline__ typename V3Val<MB>::type v3_zero() {
     if constexpr (MB == 1) return 0.f; else return f32x4{0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ float v3_fma(float a, float b, float c) { return fmaf(a, b, c); }
-__device__ __forceinline__ f32x4 v3_fma(const f32x4& a, float b, const f32x4& c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
 
 // compile-time loop over 0 .. N-1 (indices as integral constants: ring slots, row sets and accumulators stay in registers)
 template <int I, int N, typename F> __device__ __forceinline__ void v3_static_for(F&& f) {
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
             lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[2], c8, lo, 0, 0, 0);
             hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[3], c8, hi, 0, 0, 0);
         };
-        auto zero_term = [&](const f32x4& lo, const f32x4& hi) { return (v3_pick<MB>(lo) + v3_pick<MB>(hi)) * -0.0009765625f; };
+        auto zero_term = [&](const f32x4& lo, const f32x4& hi) { return v3_pick<MB>(lo) + v3_pick<MB>(hi); };      // -1024 sum(x)
         // XG: address of the fragments of the step XD ahead, clamped to the wave's last step
         const uint8_t* const xlast = xp + (size_t)(nsw - 1) * (NW * 256);
         const uint8_t* xq = xp;
@@ -596,9 +597,10 @@ __global__ __launch_bounds__(V3_LAUNCH_THREADS(NW)) void gemv_v3_kernel(const ui
         // the MFMAs of the next one -- nothing reads an MFMA result right behind the MFMA (that wait was ~10 % of a launch).
         val_t pv_lo = v3_zero<MB>(), pv_hi = v3_zero<MB>(), pv_B = v3_zero<MB>();
         uint32_t pv_szw = 0;
-        auto fold = [&](val_t& dst) {
+        auto fold = [&](val_t& dst) {           // three FMAs per value (MB == 2: six packed ones for the lane's four batch rows)
             const h2 sz2 = as_h2(pv_szw);
-            dst = dst + ((float)sz2[0] * (pv_lo + 0.0625f * pv_hi) + (float)sz2[1] * pv_B);
+            dst = v3_fma_s<MB>((float)sz2[0], v3_fma_s<MB>(0.0625f, pv_hi, pv_lo), dst);
+            dst = v3_fma_s<MB>((float)sz2[1] * -0.0009765625f, pv_B, dst);
         };
         // one (step, row set): xc = the step's fragments, xnx = the next step's (fetched at the step's first row set, their bias
         // sums formed behind its last); prev_rs = the row set of the previous consume (whose products are folded here)
