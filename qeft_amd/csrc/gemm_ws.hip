@@ -213,9 +213,12 @@ __global__ __launch_bounds__(WS_NW * 64) void gemm_ws_kernel(WsArgs a) {
         const uint8_t* const sp0 = szl + (size_t)wave * 64 + nl * 4;
         const uint8_t* const sp_last = sp0 + (size_t)(nsw - 1) * (NW * 64);
         const uint8_t* sp = sp0 + (size_t)rot * (NW * 64);
-        accv alo = accv{}, ahi = accv{};
+        // -1024 S_lo, -1024 S_hi of the step's fragments per chunk (S = the sum of x over the low- / high-nibble positions): whole
+        // MFMA results, the C operand of the step's product MFMAs (gemv_v3.h step 4) -- the products come out without the 1024
+        // bias and the fold is three FMAs per value; zB = -1024 sum(x) of the step for the zero-point term
+        f32x4 A0[MC], A1[MC];
+        accv zB = accv{};
         auto bias_sums = [&](const v3h8 (&x4)[MC][4]) {
-            f32x4 A0[MC], A1[MC];
             ws_for<MC>([&](auto c) {
                 constexpr int cc = decltype(c)::value;
                 A0[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[cc][0], c8, z4, 0, 0, 0);
@@ -223,8 +226,11 @@ __global__ __launch_bounds__(WS_NW * 64) void gemm_ws_kernel(WsArgs a) {
                 A0[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[cc][2], c8, A0[cc], 0, 0, 0);
                 A1[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x4[cc][3], c8, A1[cc], 0, 0, 0);
             });
-            alo = join(A0);
-            ahi = join(A1);
+            zB = join(A0) + join(A1);
+        };
+        auto splat = [&](float v) {
+            if constexpr (MC == 1) return accv{v, v, v, v};
+            else return accv{v, v, v, v, v, v, v, v};
         };
         // one (step, row set): xc = the step's fragments, xld = the set the fragments of the step XD ahead are loaded into
         v3h8 xf[MC][4];                                         // the current step's A fragments
@@ -251,13 +257,14 @@ __global__ __launch_bounds__(WS_NW * 64) void gemm_ws_kernel(WsArgs a) {
             f32x4 Plo[MC], Phi[MC];
             ws_for<MC>([&](auto c) {
                 constexpr int cc = decltype(c)::value;
-                Plo[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[cc][0], __builtin_bit_cast(v3h8, bf[0]), z4, 0, 0, 0);
-                Phi[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[cc][1], __builtin_bit_cast(v3h8, bf[1]), z4, 0, 0, 0);
+                Plo[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[cc][0], __builtin_bit_cast(v3h8, bf[0]), A0[cc], 0, 0, 0);
+                Phi[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[cc][1], __builtin_bit_cast(v3h8, bf[1]), A1[cc], 0, 0, 0);
                 Plo[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[cc][2], __builtin_bit_cast(v3h8, bf[2]), Plo[cc], 0, 0, 0);
                 Phi[cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xc[cc][3], __builtin_bit_cast(v3h8, bf[3]), Phi[cc], 0, 0, 0);
             });
             const h2 sz2 = as_h2(szw);
-            acc[rs] = acc[rs] + ((float)sz2[0] * ((join(Plo) + alo) + 0.0625f * (join(Phi) + ahi)) + (float)sz2[1] * ((alo + ahi) * -0.0009765625f));
+            acc[rs] = __builtin_elementwise_fma(splat((float)sz2[0]), __builtin_elementwise_fma(splat(0.0625f), join(Phi), join(Plo)), acc[rs]);
+            acc[rs] = __builtin_elementwise_fma(splat((float)sz2[1] * -0.0009765625f), zB, acc[rs]);
             if (rs == RSC - 1) sp = sp >= sp_last ? sp0 : sp + NW * 64;
         };
         // the unrolled round: a whole number of ring turns and of fragment-set turns
