@@ -512,26 +512,42 @@ class DecodeEngine:
             # "auto": the one-shot kernel if every rank can build it AND it reproduces the group's own all_reduce on a probe vector;
             # anything else falls back to the group's collective, and says so (collective_note)
             from .oneshot import OneShotAllReduce
+            # Every rank issues the same collectives of the group in the same order whatever fails locally (a rank that left the
+            # sequence early would leave its peers waiting in a collective it never joins).
             ok, why = True, None
+
+            def failed(e):
+                nonlocal ok, why
+                if ok:
+                    ok, why = False, f"{type(e).__name__}: {e}"[:200]
+
             try:
                 if self.P > self.lib.qeft_oneshot_max_world():
                     raise ValueError(f"{self.P} ranks > {self.lib.qeft_oneshot_max_world()}")
-                self.oneshot = OneShotAllReduce(s.hidden, dev, tp_group)
-                probe = torch.randn(s.hidden, generator=torch.Generator().manual_seed(1234 + self.rank)).to(dev)
-                ref = probe.clone()
-                on_cpu = dist.get_backend(tp_group) == "gloo"
-                for _ in range(3):          # both mailbox parities
-                    self.oneshot.all_reduce(probe)
-                    r = ref.cpu() if on_cpu else ref
-                    dist.all_reduce(r, group=tp_group)
-                    ref = r.to(dev)
-                torch.cuda.synchronize(dev)
-                self.oneshot.check_status()
-                # (rank-order fp32 sum vs the ring's order: equal for two ranks, within rounding beyond)
-                if not torch.allclose(probe, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())):
-                    raise RuntimeError(f"probe mismatch: max |d| {(probe - ref).abs().max().item():.3e}")
+                self.oneshot = OneShotAllReduce(s.hidden, dev, tp_group)        # (raises on every rank alike, or on none)
             except Exception as e:      # noqa: BLE001 -- any failure of the optional fast path means: use the group's collective
-                ok, why = False, f"{type(e).__name__}: {e}"[:200]
+                failed(e)
+            probe = torch.randn(s.hidden, generator=torch.Generator().manual_seed(1234 + self.rank)).to(dev)
+            ref = probe.clone()
+            on_cpu = dist.get_backend(tp_group) == "gloo"
+            for _ in range(3):              # both mailbox parities
+                if ok:
+                    try:
+                        self.oneshot.all_reduce(probe)
+                    except Exception as e:  # noqa: BLE001
+                        failed(e)
+                r = ref.cpu() if on_cpu else ref
+                dist.all_reduce(r, group=tp_group)
+                ref = r.to(dev)
+            if ok:
+                try:
+                    torch.cuda.synchronize(dev)
+                    self.oneshot.check_status()
+                    # (rank-order fp32 sum vs the ring's order: equal for two ranks, within rounding beyond)
+                    if not torch.allclose(probe, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())):
+                        raise RuntimeError(f"probe mismatch: max |d| {(probe - ref).abs().max().item():.3e}")
+                except Exception as e:      # noqa: BLE001
+                    failed(e)
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
             flag = flag if dist.get_backend(tp_group) == "gloo" else flag.to(dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=tp_group)        # every rank takes the same path

@@ -25,32 +25,50 @@ class OneShotAllReduce:
             raise ValueError(f"one-shot all-reduce is built for up to {self.lib.qeft_oneshot_max_world()} ranks, got {self.world}")
         self.n = int(n)
         self.device = torch.device(device)
+        # Every rank runs the SAME two collectives of the group whatever happens locally (a rank that raised before a collective its
+        # peers are waiting in would hang them): failures are collected, exchanged, and raised on every rank alike.
+        self.box, self._opened, err = None, [], None
+        mine = None
         with torch.cuda.device(self.device):
-            # the mailbox is a hipMalloc block of its own (an IPC handle exports the whole allocation a pointer lives in: a tensor
-            # carved out of torch's caching allocator would arrive in the peer at an offset nobody knows)
-            box = ctypes.c_void_p()
-            _lib.check(self.lib.qeft_oneshot_mailbox_alloc(self.world, self.n, ctypes.byref(box)))
-            self.box = box.value
-            self.seq = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
-            torch.cuda.synchronize(self.device)
-            handle = ctypes.create_string_buffer(64)
-            _lib.check(self.lib.qeft_oneshot_ipc_export(self.box, handle))
-            mine = bytes(handle.raw)
+            try:
+                # the mailbox is a hipMalloc block of its own (an IPC handle exports the whole allocation a pointer lives in: a
+                # tensor carved out of torch's caching allocator would arrive in the peer at an offset nobody knows)
+                box = ctypes.c_void_p()
+                _lib.check(self.lib.qeft_oneshot_mailbox_alloc(self.world, self.n, ctypes.byref(box)))
+                self.box = box.value
+                self.seq = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
+                torch.cuda.synchronize(self.device)
+                handle = ctypes.create_string_buffer(64)
+                _lib.check(self.lib.qeft_oneshot_ipc_export(self.box, handle))
+                mine = bytes(handle.raw)
+            except Exception as e:          # noqa: BLE001 -- reported to every rank below
+                err = f"rank {self.rank}: {type(e).__name__}: {e}"
             everyone = [None] * self.world
             dist.all_gather_object(everyone, mine, group=group)
-            self._opened = []
             ptrs = (ctypes.c_void_p * self.world)()
-            for r, h in enumerate(everyone):
-                if r == self.rank:
-                    ptrs[r] = self.box
-                    continue
-                p = ctypes.c_void_p()
-                _lib.check(self.lib.qeft_oneshot_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(p)))
-                self._opened.append(p)
-                ptrs[r] = p.value
+            if err is None and any(h is None for h in everyone):
+                err = f"rank {self.rank}: a peer has no mailbox to export"
+            if err is None:
+                try:
+                    for r, h in enumerate(everyone):
+                        if r == self.rank:
+                            ptrs[r] = self.box
+                            continue
+                        p = ctypes.c_void_p()
+                        _lib.check(self.lib.qeft_oneshot_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(p)))
+                        self._opened.append(p)
+                        ptrs[r] = p.value
+                except Exception as e:      # noqa: BLE001
+                    err = f"rank {self.rank}: {type(e).__name__}: {e}"
             self.ptrs = ptrs
-        dist.barrier(group=group)       # nobody writes into a mailbox that is not mapped everywhere yet
+        # doubles as the barrier: nobody writes into a mailbox that is not mapped everywhere yet
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err, group=group)
+        errs = [e for e in errs if e]
+        if errs:
+            self.close()
+            raise RuntimeError("one-shot all-reduce could not be set up: " + "; ".join(errs)[:300])
 
     def all_reduce(self, t):
         """In-place fp32 sum of `t` (n elements) over the group: one kernel on the current stream."""
