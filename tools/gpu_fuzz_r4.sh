@@ -8,4 +8,5 @@ timeout -k 10 900 python tools/fuzz_parity.py 120 large > gpurun_out/r04_fuzz_pa
 timeout -k 10 900 python tools/fuzz_parity.py 80 v3 > gpurun_out/r04_fuzz_parity_v3.txt 2>&1 || rc=1; tail -1 gpurun_out/r04_fuzz_parity_v3.txt
 timeout -k 10 900 python tools/fuzz_parity.py 160 ref > gpurun_out/r04_fuzz_parity_ref.txt 2>&1 || rc=1; tail -1 gpurun_out/r04_fuzz_parity_ref.txt
 timeout -k 10 900 python tools/fuzz_parity.py 40 w3gemm > gpurun_out/r04_fuzz_parity_w3gemm.txt 2>&1 || rc=1; tail -1 gpurun_out/r04_fuzz_parity_w3gemm.txt
+timeout -k 10 900 python tools/fuzz_parity.py 120 ws > gpurun_out/r04_fuzz_parity_ws.txt 2>&1 || rc=1; tail -1 gpurun_out/r04_fuzz_parity_ws.txt
 exit $rc
