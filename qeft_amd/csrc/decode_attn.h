@@ -1,5 +1,6 @@
-// Single-token attention of the decode harness (rotary + KV append + flash-decoding split), as a device-function BODY shared by
-// decode_aux.hip (the stand-alone launch) and attn_oproj.hip (round 4: attention and o_proj in one launch).
+// Single-token attention of the decode harness (rotary + KV append + flash-decoding split): the kernel of decode_aux.hip, with its
+// BODY as a device function (the round-4 lab kernel tools/attn_oproj_lab_kernel.h -- attention and o_proj in one launch, measured
+// and rejected: profiles/r04_attn_oproj_fused.txt -- runs the same body).
 #pragma once
 #include "qeft_common.h"
 
@@ -56,10 +57,10 @@ __device__ __forceinline__ size_t kcache_off(int p, int chunk, int max_seq) {
 // Parameter order: what the first loads need comes first -- the leading 13 dwords of the kernel-argument segment are
 // preloaded into SGPRs at wave launch (build flag -amdgpu-kernarg-preload-count), the rest arrives by scalar loads that
 // overlap those first vector loads.  DBG (lab only, tools/attn_timeline.py): per-wave phase stamps.
-// The kernel's BODY is a device function so that the fused attention + o_proj launch (attn_oproj.hip, round 4) can run it too:
+// The kernel's BODY is a device function so that the lab's fused attention + o_proj launch can run it too:
 // `bid` = the block's index among the attention blocks, `smem_raw` = its dynamic LDS, and -- S == 1 only -- `pub` != NULL sends
 // every output element to pub[opos] by an agent-scope (write-through) store instead of a plain store to out[opos]: readers on
-// other XCDs of the SAME launch can then be released by a flag (attn_oproj.hip).
+// other XCDs of the SAME launch can then be released by a flag (lab only; the product passes NULL).
 template <int PRE, int DH = 1, bool KFT = false, bool DBG = false, bool ALIBI = false>
 __device__ __forceinline__ void rope_attn_decode_body(uint8_t* smem_raw, const int bid, const int* __restrict__ pos_ptr,
                                                       const int* __restrict__ out_pos, const f16* __restrict__ q,

@@ -8,7 +8,7 @@
 #include <cstdlib>
 
 #include "qeft_common.h"
-#include "decode_attn.h"      // the attention kernel and its body (shared with attn_oproj.hip)
+#include "decode_attn.h"      // the attention kernel; its body is a device function (the lab tools/attn_oproj_lab_kernel.h runs it too)
 
 namespace qeft {
 
