@@ -15,10 +15,10 @@ def lib():
     return _lib.lib()
 
 
-ROWS = (16, 32, 48, 512, 640, 1376, 1728, 4096, 16 * 513, 16 * 769, 11008, 12288, 16 * 1025, 22016, 27648, 16 * 3001)
+ROWS = (16, 32, 48, 512, 640, 1376, 1728, 4096, 16 * 513, 16 * 769, 8192, 11008, 12288, 16 * 1025, 22016, 27648, 28672, 16 * 3001, 57344)
 
 
-@pytest.mark.parametrize("k", [128, 256, 384, 1024, 4096, 4224, 5120, 8192, 11008, 13824])
+@pytest.mark.parametrize("k", [128, 256, 384, 1024, 4096, 4224, 5120, 8192, 11008, 13824, 28672])
 @pytest.mark.parametrize("r", [0, 128])
 def test_all_row_counts(lib, k, r):
     if r and k == 128:

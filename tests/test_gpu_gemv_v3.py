@@ -36,6 +36,7 @@ def ref(bufs, x, r, g):
     (512, 4096, 128, 128), (4096, 4096, 128, 128), (11008, 4096, 128, 128), (4096, 11008, 128, 128),
     (5120, 5120, 128, 128), (13824, 5120, 128, 128), (5120, 13824, 128, 128), (640, 5120, 128, 128), (1728, 5120, 128, 128),
     (64, 2048, 128, 2048), (16 * 513, 256, 128, 128), (16 * 769, 256, 0, 128),
+    (8192, 8192, 128, 128), (28672, 8192, 128, 128), (8192, 28672, 128, 128),      # Llama-2-70B shapes (not a BASELINE config)
 ])
 def test_single_linear(n, k, r, g):
     from qeft_amd import _lib, qeft_cuda
