@@ -53,7 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "70b", "tiny"],
+                    help="7b: the BASELINE headline (default); 13b: BASELINE config 4's model; 70b: the Llama-2-70B shapes on one GPU "
+                         "(36 GB of packed weights; not a BASELINE config)")
     ap.add_argument("--bits", type=int, default=4, choices=[3, 4],
                     help="4: the reference's w4 checkpoint layout (BASELINE configs 1-4, the default); "
                          "3: this build's 3-bit extension layout (config 5)")
@@ -476,8 +478,8 @@ def main():
         group = dist.group.WORLD
 
     import dataclasses
-    from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, DecodeEngine, QuantLlama, tiny_shape
-    base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B,
+    from qeft_amd.llama import LLAMA2_7B, LLAMA2_13B, LLAMA2_70B, DecodeEngine, QuantLlama, tiny_shape
+    base = {"7b": LLAMA2_7B, "13b": LLAMA2_13B, "70b": LLAMA2_70B,
             "tiny": tiny_shape(n_layers=4, hidden=512, inter=1024, n_heads=4, vocab=1024)}[args.model]
     ctx0 = CONTEXT + args.warmup                                   # position of the first timed token
     shape = dataclasses.replace(base, max_seq=max(512, (ctx0 + args.steps + 128 + 8 + 15) // 16 * 16), bits=args.bits)
@@ -783,6 +785,14 @@ def main():
                 extras["model_13b"] = model_13b_record(dev)
             except Exception as e:
                 print(f"[bench] model_13b failed: {type(e).__name__}: {e}", file=sys.stderr)
+            # ---- where the same launches land when the fixed part is amortised: the Llama-2-70B shapes (36 GB packed, grouped-query
+            #      attention) on the one GPU -- not a BASELINE config, context for roofline.frac
+            try:
+                from qeft_amd.llama import LLAMA2_70B
+                torch.cuda.empty_cache()
+                extras["model_70b"] = model_13b_record(dev, steps=48, warmup=16, base=LLAMA2_70B)
+            except Exception as e:
+                print(f"[bench] model_70b failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     if rank == 0:
         ms = dt * 1e3 / args.steps

@@ -48,6 +48,7 @@ class LlamaShape:
 
 LLAMA2_7B = LlamaShape(4096, 11008, 32, 32, 32, 32000, name="llama-2-7b")
 LLAMA2_13B = LlamaShape(5120, 13824, 40, 40, 40, 32000, name="llama-2-13b")
+LLAMA2_70B = LlamaShape(8192, 28672, 80, 64, 8, 32000, name="llama-2-70b")      # (grouped-query attention; not a BASELINE config)
 
 
 def tiny_shape(n_layers=2, hidden=256, inter=512, n_heads=2, vocab=512, max_seq=64, n_out=128):
