@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void oneshot_allreduce_kernel(OsArgs a) {
         const os_gu64* mine = (const os_gu64*)a.box[a.rank] + par + i0;
         float s0 = 0.f, s1 = 0.f;
         const long long t0 = wall_clock64();
-        bool dead = false;
+        // a wait that gave up in an EARLIER call leaves its code in status[0]: this group is out of step for good, so later calls do
+        // not wait at all (they would each sit out the whole timeout) -- the caller reads the status word and falls back
+        bool dead = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         for (int s = 0; s < a.world; ++s) {
             unsigned long long q0, q1;
             for (unsigned spins = 0;; ++spins) {

@@ -49,7 +49,7 @@ def _szp_shadow(scales, zeros, n, k, group_size):
     if not _SZP_CACHE_ON:
         return None
     key = (id(scales), id(zeros))
-    stamp = (scales._version, zeros._version, n, k, group_size)
+    stamp = (scales._version, zeros._version, scales.data_ptr(), zeros.data_ptr(), n, k, group_size)      # (.data = ... keeps object and version)
     ent = _SZP_CACHE.get(key)
     if ent is not None and ent[0]() is scales and ent[1]() is zeros and ent[2] == stamp:
         return ent[3]

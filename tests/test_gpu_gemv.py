@@ -202,6 +202,11 @@ def test_shim_scale_shadow_follows_the_tensors():
     y3 = qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"], 1, n, k, G)
     yref = O.quant_linear(x.cpu().numpy(), bufs["qweight"], t["scales"].cpu().numpy(), bufs["scaled_zeros"], bufs["oweight"], None, G)
     assert rel_err(y3.cpu().numpy(), yref.astype(np.float64)) < REL_TOL
-    del t, y1, y2, y3
+    # `.data = ...` keeps the tensor object and its version counter: the storage address in the stamp catches it
+    t["scales"].data = (t["scales"].data * 0.5).clone()
+    y4 = qeft_cuda.gemv_4bit_qeft(x, t["qweight"], t["scales"], t["scaled_zeros"], t["oweight_interleaved"], 1, n, k, G)
+    yref4 = O.quant_linear(x.cpu().numpy(), bufs["qweight"], t["scales"].cpu().numpy(), bufs["scaled_zeros"], bufs["oweight"], None, G)
+    assert rel_err(y4.cpu().numpy(), yref4.astype(np.float64)) < REL_TOL
+    del t, y1, y2, y3, y4
     gc.collect()
     assert len(qeft_cuda._SZP_CACHE) == 0
