@@ -117,7 +117,30 @@ def _collective_rank(rank, world, port, q):
         import hashlib
         exact = all(torch.equal(o, e.float()) for o, e in zip(outs, expect))       # two fp32 terms: the rounded exact sum
         digest = hashlib.sha256(b"".join(o.numpy().tobytes() for o in outs)).hexdigest()
-        q.put((rank, exact, digest, graph_ok))        # (plain values: tensors through the queue outlive their process badly)
+        # a peer that never arrives: the call gives up after its 2 s and records a code; every call after that returns at once
+        # (the group is out of step for good -- the caller reads the status word and falls back).  Last act of this object.
+        dist.barrier()
+        quick = True
+        if rank == 0:
+            import time
+            lonely = torch.zeros(n, dtype=torch.float32, device=dev)
+            t0 = time.time()
+            ar.all_reduce(lonely)
+            torch.cuda.synchronize()
+            first = time.time() - t0
+            t0 = time.time()
+            for _ in range(3):
+                ar.all_reduce(lonely)
+            torch.cuda.synchronize()
+            later = time.time() - t0
+            gave_up = False
+            try:
+                ar.check_status()
+            except RuntimeError:
+                gave_up = True
+            quick = gave_up and 1.0 < first < 6.0 and later < 0.5
+        dist.barrier()
+        q.put((rank, exact, digest, graph_ok and quick))        # (plain values: tensors through the queue outlive their process badly)
     finally:
         dist.destroy_process_group()
 
