@@ -917,15 +917,15 @@ bool gemm_w4_pair64_ok(int M, int n2, int K, int G, int n_out) {
            (size_t)M * K * 2 < (1ull << 32) && (size_t)(n2 / 4) * K * 2 < (1ull << 32);
 }
 
-// 256-row or 128-row loader-wave tile?  One block per CU either way; a launch takes ceil(tiles / 256) rounds of blocks and a
-// 256-row block takes ~1.7x a 128-row block (it is the more efficient one per flop).  M >= 1024 with >= 224 tiles of 256 rows is
-// round 2's rule and stays; below that the 256-row tile also wins where the 128-row tiles would need a second, mostly empty round
-// (11008 x 4096 at M = 512: 344 tiles of 128 rows = 2 rounds, 172 tiles of 256 rows = one).
+// 256-row or 128-row loader-wave tile?  One block per CU either way; a launch takes ceil(tiles / 256) rounds of blocks, a partly
+// filled round costs a whole one, and a 256-row block takes ~1.65x a 128-row block (it is the more efficient one per flop:
+// profiles/r04_gemm_m_sweep.txt -- 52-57 us against 31-35 us per round at K = 4096).  The tile with the cheaper sum of rounds wins,
+// ties go to the 256-row tile.  Round 4 dropped round 2's unconditional "M >= 1024 -> 256 rows": 11008 x 4096 at M = 1408 is 516
+// tiles of 256 rows = THREE rounds (167 us) but 946 of 128 rows = four cheaper ones.
 static bool gemm_v3_prefers_256(int M, int N) {
     const int nb = (N + G3_BN - 1) / G3_BN, t8 = ((M + G3_BM - 1) / G3_BM) * nb, t4 = ((M + 127) / 128) * nb;
-    if (t8 >= 224 && M >= 1024) return true;
     if (M <= 256 || t8 < 129) return false;
-    return 1.7 * ((t8 + 255) / 256) < 1.0 * ((t4 + 255) / 256);
+    return 1.65 * ((t8 + 255) / 256) <= 1.0 * ((t4 + 255) / 256);
 }
 
 // Split factor of the 128-row loader-wave tier (round 3): S blocks per tile when the tiles alone fill less than 3/4 of the CUs --
@@ -1775,12 +1775,11 @@ int gemm_w4_dx_split(int M, int N, int K) {
 // bits == 3: qw is the 3-bit extension layout; only the loader-wave tier reads it (hipErrorNotSupported otherwise: the caller
 // expands to the 4-bit layout, qeft_expand_w3, and comes back with bits == 4)
 // Tile of the loader-wave dX kernel for a shape: 8 (256 rows), 4 (128 rows) or 0 (the older kernels).  Same counting of rounds of
-// blocks as the forward's choice: 256-row tiles from 224 tiles on at M >= 1024, or where 128-row tiles would need a second round;
-// 128-row tiles from 112 tiles on (M > 128).
+// blocks as the forward's choice (gemm_v3_prefers_256; dx256 takes ~1.6x a dx128v3 block: 68 against 43 us per round on 4096^2):
+// the cheaper sum of rounds, ties to the 256-row tile; 128-row tiles from 112 tiles on (M > 128).
 static int gemm_dx_v3_tile(int M, int K) {
     const int kb = K / D3_BK, t8 = ((M + D3_BM - 1) / D3_BM) * kb, t4 = ((M + 127) / 128) * kb;
-    if (t8 >= 224 && M >= 1024) return 8;
-    if (M > 256 && t8 >= 129 && 1.7 * ((t8 + 255) / 256) < 1.0 * ((t4 + 255) / 256)) return 8;
+    if (M > 256 && t8 >= 129 && 1.6 * ((t8 + 255) / 256) <= 1.0 * ((t4 + 255) / 256)) return 8;
     if (t4 >= 112 && M > 128) return 4;
     return 0;
 }

@@ -204,7 +204,7 @@ def test_variant_names_follow_the_routing():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("m,n,k,r,g", [(1100, 5896, 512, 64, 64), (2148, 4096, 1024, 0, 128), (1024, 7168, 640, 128, 128)])
+@pytest.mark.parametrize("m,n,k,r,g", [(1100, 5896, 512, 64, 64), (2148, 3584, 1024, 0, 128), (1024, 7168, 640, 128, 128)])
 def test_gemm_large_m_tile_edges(m, n, k, r, g):
     """The 256 x 128 tile of the M >= 2048 tier with everything ragged: M not a multiple of 256, N not a multiple of 128,
     group size 64, 64 / 0 outlier columns, a K loop barely longer than the DMA ring -- full output vs the oracle."""

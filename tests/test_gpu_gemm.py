@@ -117,7 +117,8 @@ def test_doweight_block_widths_ragged(m, n, k, r):
     assert rel_err(dow.cpu().numpy(), ref) < REL_TOL
 
 
-@pytest.mark.parametrize("m,n,k,r,fused", [(2048, 3584, 512, 128, True), (2000, 3592, 384, 0, True), (1100, 7176, 448, 64, True),
+@pytest.mark.parametrize("m,n,k,r,fused", [(2048, 3584, 512, 128, True), (2000, 3592, 384, 0, True), (1100, 5896, 448, 64, True),
+                                            (1100, 7176, 448, 64, False),      # 285 tiles of 256 rows = two rounds: another tier is cheaper
                                             (64, 512, 512, 128, False), (300, 1024, 256, 0, False)])
 def test_gemm_silu_mul_epilogue(m, n, k, r, fused):
     """silu(gate) * (x . W^T + bias) from one launch on the 256-row tier == the GEMM followed by qeft_silu_mul, bit for bit
