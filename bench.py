@@ -548,20 +548,10 @@ def main():
         nonlocal graph_ok, graph_capture_error
         if world == 1 or eng.oneshot is None:
             return False
-        torch.cuda.synchronize(dev)
-        st_word = int(eng.oneshot.status[0].item())
-        flag = torch.tensor([st_word], dtype=torch.int64, device=dev if not shared else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        code = int(flag.item())
-        if not code:
+        if eng.verify_collective(when):
             return False
-        eng.oneshot.close()
-        eng.oneshot, eng.collective = None, "rccl"
-        eng.collective_note = (f"the one-shot collective gave up during {when} (largest status word over the ranks {code:#x}): "
-                               "the group's all-reduce from there")
         if rank == 0:
             print(f"[bench] {eng.collective_note}", file=sys.stderr)
-        eng.graph, eng.graphs = None, {}
         eng.use_graph = not (args.no_graph or shared)
         graph_ok, graph_capture_error = capture_graphs()
         build_context()

@@ -677,6 +677,29 @@ class DecodeEngine:
     def reset(self):
         self.set_position(0)
 
+    def verify_collective(self, when="a run"):
+        """Tensor-parallel engines with the one-shot collective: True if no rank's status word holds a give-up code.  Otherwise the
+        collective is dropped on EVERY rank alike (one MAX all-reduce of the group says so), the captured graphs are discarded and
+        the group's own all-reduce serves from here (`collective` becomes "rccl", the reason goes to `collective_note`): results
+        produced since the last check are not to be trusted, the caller re-runs them.  Synchronises; call it at token boundaries."""
+        if self.oneshot is None:
+            return True
+        import torch.distributed as dist
+        torch.cuda.synchronize(self.dev)
+        word = int(self.oneshot.status[0].item())
+        on_cpu = dist.get_backend(self.tp_group) == "gloo"
+        flag = torch.tensor([word], dtype=torch.int64, device="cpu" if on_cpu else self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.tp_group)
+        code = int(flag.item())
+        if not code:
+            return True
+        self.oneshot.close()
+        self.oneshot, self.collective = None, "rccl"
+        self.collective_note = (f"the one-shot collective gave up during {when} (largest status word over the ranks {code:#x}): "
+                                "the group's all-reduce from there")
+        self.graph, self.graphs = None, {}
+        return False
+
     def set_position(self, t):
         """The next token to be fed sits at position t (the KV caches hold positions < t)."""
         if not 0 <= int(t) <= self.m.shape.max_seq:
