@@ -44,7 +44,32 @@ __global__ __launch_bounds__(NT) void lm_head(const float* __restrict__ h32, con
     }
     const int r_end = min(vocab, (int)(blockIdx.x + 1) * rows_per_block);
     int r = blockIdx.x * rows_per_block + wave;
-    u32x4 buf[RIF][LPR];
+    if constexpr (RIF == 0) {      // two row buffers with alternating roles, no register copies: the loads of one row stay in flight across the other's dots
+        u32x4 A[LPR], B[LPR];
+        auto ld = [&](int row, u32x4 (&dst)[LPR]) {
+            const u32x4* p = (const u32x4*)(W + (size_t)min(row, vocab - 1) * H) + lane;
+#pragma unroll
+            for (int c = 0; c < LPR; ++c) dst[c] = __builtin_nontemporal_load(p + c * 64);
+        };
+        auto dots = [&](const u32x4 (&src)[LPR], int row) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < LPR; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, src[c][j]), xh[c][j], acc, false);
+            acc = wave_sum(acc);
+            if (lane == 0 && row < r_end) logits[row] = (f16)acc;
+        };
+        ld(r, A);
+        for (; r < r_end; r += 2 * NWV) {
+            ld(r + NWV, B);
+            dots(A, r);
+            ld(r + 2 * NWV, A);
+            dots(B, r + NWV);
+        }
+        return;
+    }
+    u32x4 buf[RIF == 0 ? 1 : RIF][LPR];
     auto load_row = [&](int row, u32x4 (&dst)[LPR]) {
         const u32x4* p = (const u32x4*)(W + (size_t)min(row, vocab - 1) * H) + lane;
 #pragma unroll
@@ -104,6 +129,9 @@ int main() {
         run<0, 512, 2>("product form", 1024, h, g, W, out);
         run<0, 256, 3>("4-wave blocks, 3 rows in flight", 1024, h, g, W, out);
         run<0, 512, 3>("3 rows in flight", 512, h, g, W, out);
+        run<0, 512, 0>("two buffers, alternating roles", 512, h, g, W, out);
+        run<1, 512, 0>("two buffers, alternating, no norm", 512, h, g, W, out);
+        run<0, 256, 0>("two buffers, alternating, 4-wave blocks", 1024, h, g, W, out);
     }
     return 0;
 }
